@@ -1,0 +1,200 @@
+/*
+ * mpc_hip.h -- C-ABI of libmpc_hip.so, the MI355X (gfx950) implementation of the afb2001/mpc
+ * trajectory-optimisation hot path: candidate control search -> VehicleState forward simulation with the
+ * estimated current applied -> tracking cost against the reference trajectory -> argmin.
+ *
+ * This is the drop-in boundary of SURVEY.md section 8b.  The reference has no FFI: its hot path is the body
+ * of Controller::mpc (src/controller.cpp:26-205) calling VehicleState::simulate (src/VehicleState.h:43-55)
+ * and Controller::compareStates (src/controller.cpp:231-241).  A maintainer keeps controller.h unchanged and
+ * replaces the body of Controller::mpc by the marshalling shown in INTEGRATION.md, which calls the entry
+ * points below.  Every entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs; no C++ types, no exceptions, no torch types.
+ *   - every function returns an mpc_status (0 = ok); mpc_hip_status_string() gives the text, including the
+ *     three std::runtime_error texts of controller.cpp:37,196,202 so the C++ wrapper can re-throw them.
+ *   - pointers named h_* are host memory, d_* are device memory on the handle's GPU.  The library never
+ *     keeps a caller pointer after the call returns.
+ *   - a handle owns its device buffers and may be used by one thread at a time; Controller holds two
+ *     (SURVEY.md section 7 hard part 7: up to two mpc() calls overlap).
+ *   - headings are compass headings in radians (0 = north = +y, clockwise), as path_planner_common State.
+ *   - there is NO CPU fallback: without a usable HIP device mpc_hip_create fails with MPC_ERR_NO_DEVICE.
+ */
+#ifndef MPC_HIP_H
+#define MPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_HIP_ABI_VERSION 1
+#define MPC_MAX_DEPTH 64        /* search depth D in 1-s scoring levels (BASELINE configs use 20 and 30)   */
+#define MPC_MAX_SUBSTEPS 64     /* Euler substeps per level S (11 reference-native, 20 for 0.05 s steps)    */
+
+typedef enum {
+    MPC_OK = 0,
+    MPC_ERR_INVALID = 1,            /* bad argument (message via mpc_hip_last_error)                         */
+    MPC_ERR_NO_DEVICE = 2,          /* no HIP device / device index out of range                            */
+    MPC_ERR_HIP = 3,                /* a HIP runtime call failed                                            */
+    MPC_ERR_EMPTY_PLAN = 4,         /* controller.cpp:37  "Cannot run MPC on an empty plan"                 */
+    MPC_ERR_NO_ITERATION = 5,       /* controller.cpp:196 "MPC failed to complete a single iteration"       */
+    MPC_ERR_NON_FINITE = 6,         /* controller.cpp:202 "MPC selected non-finite controls"                */
+    MPC_ERR_STALE_TRAJECTORY = 7,   /* controller.cpp:30-32,83-86: trajectory number no longer valid        */
+    MPC_ERR_TOO_LARGE = 8           /* exceeds MPC_MAX_DEPTH / MPC_MAX_SUBSTEPS / memory limits             */
+} mpc_status;
+
+typedef enum {
+    /* "FP32 mode" of BASELINE.json: the fast kernel.  State is integrated in FP64 (MI355X runs FP64 vector
+     * math at half the FP32 rate) with the model algebraically streamlined: heading carried as (sin, cos)
+     * and advanced by a polynomial rotation, divisions by reciprocals, reciprocal-sqrt + Newton, FP32
+     * atan2 on an FP64 cross/dot pair.  Contract: per-candidate cost within 1e-5 relative of the reference
+     * (measured: far tighter), and the SAME chosen candidate, guaranteed by re-evaluating every
+     * candidate within MPC_REFINE_REL of the minimum with the strict kernel. */
+    MPC_PREC_FAST = 0,
+    /* "FP64 validation mode": the reference's operation order statement by statement, no FMA contraction,
+     * IEEE divide/sqrt, ocml sin/cos/atan2/exp.  Contract: cost within 1e-12 relative, same argmin. */
+    MPC_PREC_F64 = 1
+} mpc_precision;
+
+#define MPC_REFINE_REL 1.0e-6
+
+typedef enum {
+    MPC_SELECT_LAST_STEP = 0,       /* the reference's rule: compare the LAST level's score, controller.cpp:155-166 */
+    MPC_SELECT_CUMULATIVE = 1       /* opt-in: compare the cumulative Score of controller.cpp:156            */
+} mpc_selection;
+
+/* One reference-trajectory checkpoint: DubinsPlan::sample at start.time + (i+1)*1 s (controller.cpp:96-98). */
+typedef struct { double x, y, heading, speed; } mpc_checkpoint;
+
+/* State after one level, as MpcState (controller.h:28-34) + VehicleState members (VehicleState.h:68-80). */
+typedef struct {
+    double x, y, heading, speed;    /* State; time is start_time + level (candidate independent)             */
+    double rpm, course_made_good, speed_over_ground;
+    double rudder, throttle;        /* MpcState::LastRudder / LastThrottle: the control that led INTO this state */
+    double score;                   /* MpcState::Score: cumulative                                           */
+} mpc_level_state;
+
+/* One MPC problem = everything Controller::mpc reads (controller.cpp:40-45, 59-61, 70-73, 96-98, 150, 231-241). */
+typedef struct {
+    double start_x, start_y, start_heading, start_speed;   /* startState (rpm derived, VehicleState.h:21)    */
+    double last_rudder, last_throttle;                      /* m_LastRudder / m_LastThrottle, controller.cpp:71-72 */
+    double current_x, current_y;                            /* m_DisturbanceEstimate, controller.cpp:150       */
+    double w_distance, w_heading, w_speed;                  /* controller.cpp:240                              */
+    double rudder_granularity, throttle_granularity;        /* controller.cpp:43-44 (tree search only)         */
+    double min_rudder, mid_rudder, max_rudder;              /* controller.h:146                                */
+    double min_throttle, max_throttle;                      /* controller.h:147                                */
+    double tolerance;                                       /* c_Tolerance, controller.h:231                   */
+    int32_t depth;                                          /* D: levels = checkpoints supplied                */
+    int32_t n_substeps;                                     /* S: Euler substeps per level                     */
+    mpc_checkpoint checkpoints[MPC_MAX_DEPTH];              /* [depth]                                         */
+    double substeps[MPC_MAX_SUBSTEPS];                      /* [n_substeps] lengths from VehicleState.h:49-53  */
+} mpc_problem;
+
+typedef struct {
+    int32_t  status;                /* mpc_status of this problem                                            */
+    int32_t  levels;                /* D of the returned trajectory (tree search: deepest COMPLETED level)   */
+    uint64_t best_ordinal;          /* winning candidate ordinal / DFS leaf ordinal                          */
+    double   best_last;             /* its last-level score (controller.cpp:160 minScore)                    */
+    double   best_cumulative;       /* its cumulative Score                                                  */
+    double   first_rudder, first_throttle;   /* overallBestTrajectory[1].LastRudder/LastThrottle, :204        */
+    uint64_t evaluated;             /* candidates (leaves) scored                                            */
+    uint64_t rollout_steps;         /* estimate() calls this solve performed (the unit of the steps/s metric) */
+    uint32_t refined;               /* candidates re-evaluated by the strict kernel                          */
+    uint32_t reserved;
+    float    kernel_ms;             /* HIP-event time of the dominant rollout kernel(s) of this call         */
+    float    total_ms;              /* HIP-event time from first launch to last kernel end                   */
+    mpc_level_state trajectory[MPC_MAX_DEPTH + 1];   /* [levels+1]; [0] = start (controller.cpp:185-188)      */
+} mpc_result;
+
+typedef struct mpc_hip_handle mpc_hip_handle;
+
+/* ---- library ------------------------------------------------------------------------------------------ */
+int         mpc_hip_abi_version(void);
+const char *mpc_hip_status_string(int status);
+/* text of the last failure on this thread (HIP error string, argument that was rejected) */
+const char *mpc_hip_last_error(void);
+
+/* Fill the fields that have reference defaults (cfg/mpc.cfg:8-15, controller.h:146-147,231); zero the rest. */
+void        mpc_hip_default_problem(mpc_problem *p);
+/* VehicleState.h:49-53: the substep lengths simulate() uses for duration t, written to out[cap].
+ * Returns the count (11 for t = 1.0: ten of 0.1 and one of 1.39e-16). */
+int         mpc_hip_substep_schedule(double t, double *out, int cap);
+
+/* Create a handle on HIP device `device`.  stream: a hipStream_t to launch on, or NULL for a stream the
+ * handle creates.  Replaces nothing in the reference (it has no device). */
+int         mpc_hip_create(int device, void *stream, mpc_hip_handle **out);
+void        mpc_hip_destroy(mpc_hip_handle *h);
+int         mpc_hip_synchronize(mpc_hip_handle *h);
+
+/* ---- explicit candidate sets (BASELINE configs 2, 3) ----------------------------------------------------
+ * Replaces, per candidate i, the chain of controller.cpp:149-156 over `depth` levels:
+ *   state = state.simulate(r[l][i], t[l][i], level, current)   -- here as n_substeps estimate() calls
+ *   score = compareStates(checkpoint[l], state);  Score += score
+ * and the first-strict-minimum selection of controller.cpp:158-166.
+ * d_rudders / d_throttles: device, FP32, level-major [depth][n] (SoA: lane i reads element l*n + i).
+ * d_cost_last / d_cost_cum: device, FP64 [n], may be NULL.  h_result: host. */
+int         mpc_hip_eval_candidates(mpc_hip_handle *h, const mpc_problem *h_problem,
+                                    const float *d_rudders, const float *d_throttles, uint64_t n,
+                                    int precision, int selection,
+                                    double *d_cost_last, double *d_cost_cum, mpc_result *h_result);
+
+/* ---- seeded candidate sets generated on the device (BASELINE configs 4, 5) -------------------------------
+ * Same computation; the controls of candidate `ordinal` at level l come from include/mpc_candidates.h
+ * (seed, ordinal, l).  Evaluates ordinals first_ordinal .. first_ordinal + count - 1 (this GPU's shard of a
+ * larger set: SURVEY.md section 8e); best_ordinal is the GLOBAL ordinal.  Costs are indexed by
+ * ordinal - first_ordinal. */
+int         mpc_hip_eval_seeded(mpc_hip_handle *h, const mpc_problem *h_problem, uint64_t seed,
+                                uint64_t first_ordinal, uint64_t count, int precision, int selection,
+                                double *d_cost_last, double *d_cost_cum, mpc_result *h_result);
+
+/* Batched form (config 5): n_problems independent problems, each with its own seed and `count` candidates
+ * (ordinals 0..count-1).  h_results[n_problems].  d_cost_last/d_cost_cum: [n_problems][count] or NULL. */
+int         mpc_hip_eval_seeded_batch(mpc_hip_handle *h, const mpc_problem *h_problems, const uint64_t *h_seeds,
+                                      uint32_t n_problems, uint64_t count, int precision, int selection,
+                                      double *d_cost_last, double *d_cost_cum, mpc_result *h_results);
+
+/* Split form of the batched call for callers that keep problems resident (bench, fleet simulation):
+ * upload once, then run any number of solves with no host->device traffic but the launch itself. */
+int         mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_problems, const uint64_t *h_seeds,
+                                    uint32_t n_problems);
+int         mpc_hip_run_seeded(mpc_hip_handle *h, uint64_t first_ordinal, uint64_t count, int precision,
+                               int selection, double *d_cost_last, double *d_cost_cum);
+int         mpc_hip_run_candidates(mpc_hip_handle *h, const float *d_rudders, const float *d_throttles,
+                                   uint64_t n, int precision, int selection,
+                                   double *d_cost_last, double *d_cost_cum);
+/* copy the results of the last run (n_problems of them) to the host; synchronises the stream */
+int         mpc_hip_fetch_results(mpc_hip_handle *h, mpc_result *h_results, uint32_t n_problems);
+/* device address of the per-problem packed winners of the last run: for problem p two uint64,
+ * [2p] = bits of the winning (strict) score, [2p+1] = winning global ordinal.  Non-negative doubles order
+ * like their bit patterns, so an RCCL min-allreduce over [2p] followed by one over the ordinals of the ranks
+ * that hold the minimum combines shards. */
+int         mpc_hip_device_winners(mpc_hip_handle *h, uint64_t **d_winners);
+
+/* ---- the reference's own candidate set: limited-branching tree (BASELINE config 1) ------------------------
+ * Replaces controller.cpp:80-189: iterative-deepening DFS over the control sets of :121-146, evaluated here
+ * level-synchronously (children of all nodes of a level in DFS order, so a leaf's index IS its DFS ordinal);
+ * every deepening iteration's argmin over last-step scores falls out of one expansion.
+ * max_levels = maxIterations of controller.cpp:61 (<= problem depth).  now(ctx) / end_time reproduce the
+ * deadline of :101-103 between levels (now == NULL: frozen clock, run all levels).  max_nodes bounds the
+ * widest stored level (0 = library default); a level that does not fit ends the search like a deadline.
+ * h_level_best: optional [max_levels] per-level winners (ordinal + scores) as the deepening loop saw them. */
+typedef double (*mpc_time_fn)(void *ctx);
+typedef struct {
+    uint64_t n_leaves, best_leaf; double best_score, best_cumulative;
+} mpc_tree_level;
+int         mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels,
+                               int precision, mpc_time_fn now, void *now_ctx, double end_time,
+                               uint64_t max_nodes, mpc_tree_level *h_level_best, mpc_result *h_result);
+
+/* ---- single rollout (VehicleState::simulate itself, VehicleState.h:43-55) --------------------------------
+ * Runs ONE control sequence (host arrays [depth]) through the strict kernel and returns the state after every
+ * level.  Used by the host wrapper for getStateAfterCurrentControl-style calls and by the parity tests. */
+int         mpc_hip_rollout(mpc_hip_handle *h, const mpc_problem *h_problem, const double *h_rudders,
+                            const double *h_throttles, int precision, mpc_result *h_result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_HIP_H */

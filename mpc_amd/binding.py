@@ -1,0 +1,265 @@
+"""ctypes binding of libmpc_hip.so (include/mpc_hip.h).
+
+Plumbing only: no arithmetic of the hot path happens here.  Device buffers are passed as integers
+(``tensor.data_ptr()``) or as objects with a ``data_ptr()`` method (torch tensors on the handle's GPU).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpc_hip.so")
+
+MAX_DEPTH = 64
+MAX_SUBSTEPS = 64
+PREC_FAST, PREC_F64 = 0, 1
+SELECT_LAST_STEP, SELECT_CUMULATIVE = 0, 1
+REFINE_REL = 1.0e-6
+
+# every symbol include/mpc_hip.h declares (tests/test_abi.py checks the built library exports them all)
+EXPORTED_SYMBOLS = (
+    "mpc_hip_abi_version", "mpc_hip_status_string", "mpc_hip_last_error", "mpc_hip_default_problem",
+    "mpc_hip_substep_schedule", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
+    "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
+    "mpc_hip_upload_problems", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
+    "mpc_hip_device_winners", "mpc_hip_solve_tree", "mpc_hip_rollout",
+)
+
+
+class MpcError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(text)
+        self.status = status
+
+
+class Checkpoint(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("heading", C.c_double), ("speed", C.c_double)]
+
+
+class LevelState(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "x", "y", "heading", "speed", "rpm", "course_made_good", "speed_over_ground",
+        "rudder", "throttle", "score")]
+
+
+class Problem(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "start_x", "start_y", "start_heading", "start_speed", "last_rudder", "last_throttle",
+        "current_x", "current_y", "w_distance", "w_heading", "w_speed",
+        "rudder_granularity", "throttle_granularity", "min_rudder", "mid_rudder", "max_rudder",
+        "min_throttle", "max_throttle", "tolerance")] + [
+        ("depth", C.c_int32), ("n_substeps", C.c_int32),
+        ("checkpoints", Checkpoint * MAX_DEPTH), ("substeps", C.c_double * MAX_SUBSTEPS)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("levels", C.c_int32), ("best_ordinal", C.c_uint64),
+                ("best_last", C.c_double), ("best_cumulative", C.c_double),
+                ("first_rudder", C.c_double), ("first_throttle", C.c_double),
+                ("evaluated", C.c_uint64), ("rollout_steps", C.c_uint64),
+                ("refined", C.c_uint32), ("reserved", C.c_uint32),
+                ("kernel_ms", C.c_float), ("total_ms", C.c_float),
+                ("trajectory", LevelState * (MAX_DEPTH + 1))]
+
+
+class TreeLevel(C.Structure):
+    _fields_ = [("n_leaves", C.c_uint64), ("best_leaf", C.c_uint64), ("best_score", C.c_double),
+                ("best_cumulative", C.c_double)]
+
+
+TIME_FN = C.CFUNCTYPE(C.c_double, C.c_void_p)
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libmpc_hip.so.  Raises OSError if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    # One HIP runtime per process: torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Loading
+    # torch FIRST makes libmpc_hip.so bind to that copy; the other order leaves two runtimes in the process and
+    # torch then sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(p):
+        raise OSError("%s not found: build it with `make -C mpc_amd/csrc` (there is no CPU fallback)" % p)
+    L = C.CDLL(p)
+    vp, u64, i32, dp = C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)
+    PP, RP = C.POINTER(Problem), C.POINTER(Result)
+    L.mpc_hip_abi_version.restype = C.c_int
+    L.mpc_hip_status_string.argtypes = [i32]; L.mpc_hip_status_string.restype = C.c_char_p
+    L.mpc_hip_last_error.restype = C.c_char_p
+    L.mpc_hip_default_problem.argtypes = [PP]; L.mpc_hip_default_problem.restype = None
+    L.mpc_hip_substep_schedule.argtypes = [C.c_double, dp, i32]; L.mpc_hip_substep_schedule.restype = i32
+    L.mpc_hip_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.mpc_hip_destroy.argtypes = [vp]; L.mpc_hip_destroy.restype = None
+    L.mpc_hip_synchronize.argtypes = [vp]
+    L.mpc_hip_eval_candidates.argtypes = [vp, PP, vp, vp, u64, i32, i32, vp, vp, RP]
+    L.mpc_hip_eval_seeded.argtypes = [vp, PP, u64, u64, u64, i32, i32, vp, vp, RP]
+    L.mpc_hip_eval_seeded_batch.argtypes = [vp, PP, C.POINTER(u64), C.c_uint32, u64, i32, i32, vp, vp, RP]
+    L.mpc_hip_upload_problems.argtypes = [vp, PP, C.POINTER(u64), C.c_uint32]
+    L.mpc_hip_run_seeded.argtypes = [vp, u64, u64, i32, i32, vp, vp]
+    L.mpc_hip_run_candidates.argtypes = [vp, vp, vp, u64, i32, i32, vp, vp]
+    L.mpc_hip_fetch_results.argtypes = [vp, RP, C.c_uint32]
+    L.mpc_hip_device_winners.argtypes = [vp, C.POINTER(vp)]
+    L.mpc_hip_solve_tree.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, C.POINTER(TreeLevel), RP]
+    L.mpc_hip_rollout.argtypes = [vp, PP, dp, dp, i32, RP]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _check(status):
+    if status != 0:
+        L = load_library()
+        detail = L.mpc_hip_last_error().decode()
+        text = L.mpc_hip_status_string(status).decode()
+        raise MpcError(status, "%s%s" % (text, (": " + detail) if detail else ""))
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+def default_problem():
+    p = Problem()
+    load_library().mpc_hip_default_problem(C.byref(p))
+    return p
+
+
+def substep_schedule(t, cap=4096):
+    buf = (C.c_double * cap)()
+    n = load_library().mpc_hip_substep_schedule(float(t), buf, cap)
+    return np.array(buf[:min(n, cap)], dtype=np.float64)
+
+
+def make_problem(start, checkpoints, substeps, last=(0.0, 0.0), current=(0.0, 0.0), weights=None, **kw):
+    """start = (x, y, heading, speed); checkpoints = iterable of (x, y, heading, speed);
+    substeps = iterable of substep lengths (one level).  Other fields keep the reference defaults."""
+    p = default_problem()
+    p.start_x, p.start_y, p.start_heading, p.start_speed = [float(v) for v in start]
+    p.last_rudder, p.last_throttle = [float(v) for v in last]
+    p.current_x, p.current_y = [float(v) for v in current]
+    if weights is not None:
+        p.w_distance, p.w_heading, p.w_speed = [float(v) for v in weights]
+    cps = list(checkpoints)
+    sub = list(substeps)
+    if len(cps) > MAX_DEPTH or len(sub) > MAX_SUBSTEPS:
+        raise MpcError(8, "problem exceeds MPC_MAX_DEPTH / MPC_MAX_SUBSTEPS")
+    p.depth = len(cps)
+    p.n_substeps = len(sub)
+    for i, c in enumerate(cps):
+        p.checkpoints[i] = Checkpoint(*[float(v) for v in c])
+    for i, s in enumerate(sub):
+        p.substeps[i] = float(s)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Solver:
+    """One mpc_hip_handle.  ``stream`` is an integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
+    or None for a stream owned by the handle."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        _check(self._L.mpc_hip_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._n_problems = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mpc_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._L.mpc_hip_synchronize(self._h))
+
+    # ---- one-call forms ------------------------------------------------------------------------------
+    def eval_candidates(self, problem, d_rudders, d_throttles, n, precision=PREC_FAST,
+                        selection=SELECT_LAST_STEP, d_cost_last=None, d_cost_cum=None):
+        r = Result()
+        _check(self._L.mpc_hip_eval_candidates(self._h, C.byref(problem), _ptr(d_rudders), _ptr(d_throttles), n,
+                                               precision, selection, _ptr(d_cost_last), _ptr(d_cost_cum), C.byref(r)))
+        return r
+
+    def eval_seeded(self, problem, seed, first, count, precision=PREC_FAST, selection=SELECT_LAST_STEP,
+                    d_cost_last=None, d_cost_cum=None):
+        r = Result()
+        _check(self._L.mpc_hip_eval_seeded(self._h, C.byref(problem), seed, first, count, precision, selection,
+                                           _ptr(d_cost_last), _ptr(d_cost_cum), C.byref(r)))
+        return r
+
+    def eval_seeded_batch(self, problems, seeds, count, precision=PREC_FAST, selection=SELECT_LAST_STEP,
+                          d_cost_last=None, d_cost_cum=None):
+        n = len(problems)
+        arr = (Problem * n)(*problems)
+        sd = (C.c_uint64 * n)(*seeds)
+        res = (Result * n)()
+        _check(self._L.mpc_hip_eval_seeded_batch(self._h, arr, sd, n, count, precision, selection,
+                                                 _ptr(d_cost_last), _ptr(d_cost_cum), res))
+        return res
+
+    # ---- split forms -----------------------------------------------------------------------------------
+    def upload(self, problems, seeds=None):
+        n = len(problems)
+        arr = (Problem * n)(*problems)
+        sd = (C.c_uint64 * n)(*seeds) if seeds is not None else None
+        _check(self._L.mpc_hip_upload_problems(self._h, arr, sd, n))
+        self._n_problems = n
+
+    def run_seeded(self, first, count, precision=PREC_FAST, selection=SELECT_LAST_STEP, d_cost_last=None,
+                   d_cost_cum=None):
+        _check(self._L.mpc_hip_run_seeded(self._h, first, count, precision, selection, _ptr(d_cost_last),
+                                          _ptr(d_cost_cum)))
+
+    def run_candidates(self, d_rudders, d_throttles, n, precision=PREC_FAST, selection=SELECT_LAST_STEP,
+                       d_cost_last=None, d_cost_cum=None):
+        _check(self._L.mpc_hip_run_candidates(self._h, _ptr(d_rudders), _ptr(d_throttles), n, precision, selection,
+                                              _ptr(d_cost_last), _ptr(d_cost_cum)))
+
+    def fetch(self):
+        res = (Result * self._n_problems)()
+        _check(self._L.mpc_hip_fetch_results(self._h, res, self._n_problems))
+        return res
+
+    def device_winners(self):
+        p = C.c_void_p()
+        _check(self._L.mpc_hip_device_winners(self._h, C.byref(p)))
+        return p.value
+
+    # ---- tree search / single rollout --------------------------------------------------------------------
+    def solve_tree(self, problem, max_levels, precision=PREC_F64, now=None, end_time=0.0, max_nodes=0):
+        r = Result()
+        levels = (TreeLevel * max(max_levels, 1))()
+        cb = TIME_FN(lambda ctx: float(now())) if now is not None else C.cast(None, TIME_FN)
+        _check(self._L.mpc_hip_solve_tree(self._h, C.byref(problem), max_levels, precision, cb, None,
+                                          float(end_time), max_nodes, levels, C.byref(r)))
+        return r, levels
+
+    def rollout(self, problem, rudders, throttles, precision=PREC_F64):
+        r = Result()
+        n = problem.depth
+        ru = (C.c_double * n)(*[float(v) for v in rudders])
+        th = (C.c_double * n)(*[float(v) for v in throttles])
+        _check(self._L.mpc_hip_rollout(self._h, C.byref(problem), ru, th, precision, C.byref(r)))
+        return r

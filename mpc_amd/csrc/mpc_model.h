@@ -1,0 +1,198 @@
+/*
+ * mpc_model.h -- device functions of the vehicle model and tracking cost, in two precisions.
+ *
+ *   strict_*  FP64, the reference's statements in the reference's order (VehicleState.h:111-148,
+ *             controller.cpp:231-241).  Built with -ffp-contract=off, IEEE divide/sqrt, ocml libm.
+ *   fast_*    FP64 state, algebraically streamlined for the CDNA4 vector ALU (FP64 at half the FP32 rate,
+ *             transcendentals at quarter rate): no sin/cos/fmod/divide per substep.
+ *
+ * Shared per-problem data lives in LDS (staged once per workgroup by the kernels in mpc_hip.hip):
+ *   cp[l*CP_STRIDE + k]   k: 0 x, 1 y, 2 heading, 3 speed, 4 sin(heading), 5 cos(heading)
+ *   sub[s*SUB_STRIDE + k] k: 0 dt, 1 1000*dt, 2 dt/2000, 3 cx*dt, 4 cy*dt, 5 1/dt
+ */
+#ifndef MPC_MODEL_H
+#define MPC_MODEL_H
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define CP_STRIDE 6
+#define SUB_STRIDE 6
+
+namespace mpc {
+
+/* model constants, VehicleState.h:86-101 */
+constexpr double IDLE_RPM = 0.0;
+constexpr double MAX_RPM = 3200.0;
+constexpr double MAX_RPM_CHANGE_RATE = 1000.0;
+constexpr double PROP_RATIO = 0.389105058;
+constexpr double PROP_PITCH = 20.0;
+constexpr double PI = 3.14159265358979323846;
+constexpr double PI_2 = 1.57079632679489661923;
+constexpr double TWO_PI = PI * 2;
+constexpr double THREE_PI = 3 * PI;
+constexpr double MAX_RUDDER_ANGLE = PI / 6;
+constexpr double RUDDER_COEFFICIENT = 0.25;
+constexpr double RUDDER_DISTANCE = 2.0;
+constexpr double MASS = 2000.0;
+constexpr double MAX_POWER = 8948.4;
+constexpr double MAX_SPEED = 2.75;
+constexpr double MAX_PROP_SPEED = (MAX_RPM * PROP_RATIO) / PROP_PITCH;
+constexpr double MAX_FORCE = MAX_POWER / MAX_SPEED;
+constexpr double PROP_COEFFICIENT = MAX_FORCE / (MAX_PROP_SPEED * MAX_PROP_SPEED - MAX_SPEED * MAX_SPEED);
+constexpr double DRAG_COEFFICIENT = MAX_FORCE / (MAX_SPEED * MAX_SPEED * MAX_SPEED);
+
+struct Weights { double wd, wh, ws; };
+
+/* ======================================= strict FP64 ================================================== */
+struct Veh { double x, y, h, v, rpm, cmg, sog; };
+
+/* VehicleState.h:20-22 */
+__host__ __device__ inline double rpm_from_speed(double speed)
+{
+    return IDLE_RPM + (speed / MAX_SPEED) * (MAX_RPM - IDLE_RPM);
+}
+
+/* One level: simulate()'s clamps (VehicleState.h:44-47) and n_sub estimate() calls (:111-148).
+ * sin/cos of the rudder angle are loop invariant and cmg/sog are overwritten by every substep, so they are
+ * evaluated once / for the last substep only: the values are the ones the reference ends the level with. */
+__device__ inline void strict_level(Veh &s, double rudder, double throttle, const double *sub, int n_sub,
+                                    double cx, double cy)
+{
+    if (rudder < -1) rudder = -1; else if (rudder > 1) rudder = 1;
+    if (throttle < 0) throttle = 0; else if (throttle > 1) throttle = 1;
+    const double target_rpm = IDLE_RPM + throttle * (MAX_RPM - IDLE_RPM);
+    const double rudder_angle = rudder * MAX_RUDDER_ANGLE;
+    const double cos_ra = cos(rudder_angle), sin_ra = sin(rudder_angle);
+    double dx = 0, dy = 0, d_time = 1;
+    for (int k = 0; k < n_sub; k++) {
+        d_time = sub[k * SUB_STRIDE];
+        double rcr = (target_rpm - s.rpm) / d_time;
+        if (rcr > MAX_RPM_CHANGE_RATE) rcr = MAX_RPM_CHANGE_RATE;
+        else if (rcr < -MAX_RPM_CHANGE_RATE) rcr = -MAX_RPM_CHANGE_RATE;
+        s.rpm += rcr * d_time;
+
+        const double prop_rpm = PROP_RATIO * s.rpm;
+        const double prop_speed = prop_rpm / PROP_PITCH;
+        const double rudder_speed = fmax(sqrt(prop_speed), s.v);
+        const double thrust = PROP_COEFFICIENT * (prop_speed * prop_speed - s.v * s.v);
+        const double thrust_fwd = thrust * cos_ra;
+        const double rudder_speed_yaw = rudder_speed * sin_ra;
+        const double yaw_rate = RUDDER_COEFFICIENT * rudder_speed_yaw / RUDDER_DISTANCE;
+
+        /* heading = fmod(heading + yaw_rate*dt, 2pi); if (< 0) += 2pi.  For an argument in [0, 4pi) the
+         * subtraction below is exact (Sterbenz) and therefore equals fmod; elsewhere call fmod. */
+        double h = s.h + yaw_rate * d_time;
+        if (h >= TWO_PI) { h = (h < 2 * TWO_PI) ? h - TWO_PI : fmod(h, TWO_PI); }
+        else if (h < 0) { if (h <= -TWO_PI) h = fmod(h, TWO_PI); if (h < 0) h += TWO_PI; }
+        s.h = h;
+
+        const double speed = s.v;
+        const double drag = speed * speed * speed * DRAG_COEFFICIENT;
+        s.v += ((thrust_fwd - drag) / MASS) * d_time;
+        const double delta = s.v * d_time;
+        dx = delta * sin(h) + cx * d_time;
+        dy = delta * cos(h) + cy * d_time;
+        s.x += dx;
+        s.y += dy;
+    }
+    if (n_sub > 0) {
+        s.cmg = PI_2 - atan2(dy, dx);
+        s.sog = sqrt(dx * dx + dy * dy) / d_time;
+    }
+}
+
+/* path_planner_common State::headingDifference as SURVEY.md section 8c defines it (external; unpinned) */
+__device__ inline double heading_difference(double heading, double other)
+{
+    return fmod(fmod(other - heading, TWO_PI) + THREE_PI, TWO_PI) - PI;
+}
+
+/* controller.cpp:231-241 */
+__device__ inline double strict_score(const double *cp, const Veh &s, const Weights &w)
+{
+    const double heading_diff = fabs(heading_difference(cp[2], s.cmg));
+    const double speed_diff = fabs(cp[3] - s.sog);
+    const double dx = cp[0] - s.x;
+    const double dy = cp[1] - s.y;
+    const double d = exp(sqrt(dx * dx + dy * dy));
+    return w.wd * d + w.wh * heading_diff + w.ws * speed_diff;
+}
+
+/* ========================================= fast ======================================================= */
+/* heading is carried as (sh, ch) = (sin h, cos h); dx, dy are the last substep's displacement */
+struct FastVeh { double x, y, sh, ch, v, rpm, dx, dy; };
+
+/* sqrt(a) for a >= 0 from the hardware reciprocal-sqrt estimate and one coupled Newton/Goldschmidt step
+ * (relative error ~1e-16); a == 0 gives ~1e-154 instead of 0 */
+__device__ inline double fast_sqrt(double a)
+{
+    a = fmax(a, 1.0e-300);
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y;
+    const double hh = 0.5 * y;
+    const double r = fma(-hh, g, 0.5);
+    g = fma(g, r, g);
+    /* one more correction step on the residual: keeps the result within ~1 ulp */
+    const double e = fma(-g, g, a);
+    return fma(e, hh, g);
+}
+
+__device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
+{
+    rudder = fmin(fmax(rudder, -1.0), 1.0);
+    throttle = fmin(fmax(throttle, 0.0), 1.0);
+    const double target_rpm = throttle * MAX_RPM;
+    double sin_ra, cos_ra;
+    sincos(rudder * MAX_RUDDER_ANGLE, &sin_ra, &cos_ra);
+    const double kpc = PROP_COEFFICIENT * cos_ra;              /* thrust_fwd = kpc * (ps^2 - v^2)        */
+    const double kyaw = (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra;   /* yaw_rate = kyaw * rudder_speed */
+    constexpr double C_PROP = PROP_RATIO / PROP_PITCH;
+    for (int k = 0; k < n_sub; k++) {
+        const double *q = sub + k * SUB_STRIDE;
+        const double dt = q[0], max_step = q[1], dt_over_mass = q[2], cxdt = q[3], cydt = q[4];
+        /* rpm slew: rpm += clamp((target - rpm)/dt, +-1000) * dt */
+        const double step = fmin(fmax(target_rpm - s.rpm, -max_step), max_step);
+        s.rpm += step;
+        const double ps = C_PROP * s.rpm;
+        const double rudder_speed = fmax(fast_sqrt(ps), s.v);
+        const double v2 = s.v * s.v;
+        const double thrust_fwd = kpc * fma(ps, ps, -v2);
+        const double force = fma(-DRAG_COEFFICIENT, v2 * s.v, thrust_fwd);
+        /* heading += yaw_rate*dt as a rotation of (sin h, cos h); |dtheta| <= 0.05 rad for dt <= 0.1 s, where
+         * the degree-7/8 Taylor polynomials are exact to the last bit */
+        const double a = (kyaw * rudder_speed) * dt;
+        const double a2 = a * a;
+        const double sa = a * fma(a2, fma(a2, fma(a2, -1.0 / 5040, 1.0 / 120), -1.0 / 6), 1.0);
+        const double ca = fma(a2, fma(a2, fma(a2, fma(a2, 1.0 / 40320, -1.0 / 720), 1.0 / 24), -0.5), 1.0);
+        const double sh = fma(s.sh, ca, s.ch * sa);
+        const double ch = fma(s.ch, ca, -(s.sh * sa));
+        s.sh = sh; s.ch = ch;
+        s.v = fma(force, dt_over_mass, s.v);
+        const double delta = s.v * dt;
+        s.dx = fma(delta, sh, cxdt);
+        s.dy = fma(delta, ch, cydt);
+        s.x += s.dx;
+        s.y += s.dy;
+    }
+}
+
+/* tracking cost from the fast state; inv_dt_last = 1/dt of the level's last substep */
+__device__ inline double fast_score(const double *cp, const FastVeh &s, const Weights &w, double inv_dt_last)
+{
+    double dx = s.dx, dy = s.dy;
+    if (dx == 0.0 && dy == 0.0) dx = 1.0;          /* atan2(0, 0) = 0: course made good = pi/2 (east)    */
+    /* |headingDifference(ref, cmg)| = |angle between the travel direction and the reference heading| */
+    const double cross = dx * cp[5] - dy * cp[4];
+    const double dot = fma(dy, cp[5], dx * cp[4]);
+    const double heading_diff = (double)fabsf(atan2f((float)cross, (float)dot));
+    const double sog = fast_sqrt(fma(s.dx, s.dx, s.dy * s.dy)) * inv_dt_last;
+    const double speed_diff = fabs(cp[3] - sog);
+    const double ex = cp[0] - s.x, ey = cp[1] - s.y;
+    const double d = exp(fast_sqrt(fma(ex, ex, ey * ey)));
+    return fma(w.wd, d, fma(w.wh, heading_diff, w.ws * speed_diff));
+}
+
+}  // namespace mpc
+#endif

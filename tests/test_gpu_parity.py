@@ -1,0 +1,129 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances are the ones BASELINE.json's north_star states: per-candidate cost within 1e-5 relative in the
+fast ("FP32") mode, within 1e-12 relative in the FP64 validation mode, and the SAME chosen candidate/control.
+"""
+import numpy as np
+import pytest
+
+import mpc_amd as M
+from mpc_amd import workloads as W
+from helpers import oracle_seeded, oracle_explicit, oracle_args, rel_err, traj_array
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_FAST = 1e-5
+TOL_F64 = 1e-12
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
+def _run_seeded(solver, p, seed, first, count, prec, selection=M.SELECT_LAST_STEP):
+    torch = _torch()
+    last = torch.empty(count, dtype=torch.float64, device="cuda")
+    cum = torch.empty(count, dtype=torch.float64, device="cuda")
+    res = solver.eval_seeded(p, seed, first, count, prec, selection, last, cum)
+    return res, last.cpu().numpy(), cum.cpu().numpy()
+
+
+@pytest.mark.parametrize("prec,tol", [(M.PREC_F64, TOL_F64), (M.PREC_FAST, TOL_FAST)])
+@pytest.mark.parametrize("cfg", ["config2", "config3"])
+def test_seeded_costs_and_choice(solver, prec, tol, cfg):
+    p = W.config2_problem() if cfg == "config2" else W.config3_problem()
+    n = 8192
+    res, last, cum = _run_seeded(solver, p, W.SEED, 0, n, prec)
+    o_last, o_cum, o_best = oracle_seeded(p, W.SEED, 0, n)
+    e_last, e_cum = rel_err(last, o_last), rel_err(cum, o_cum)
+    print("%s prec=%d max rel err last=%.3e cum=%.3e refined=%d kernel_ms=%.3f" % (
+        cfg, prec, e_last.max(), e_cum.max(), res.refined, res.kernel_ms))
+    assert e_last.max() <= tol and e_cum.max() <= tol
+    assert res.status == 0
+    assert res.best_ordinal == o_best.best_index
+    # the winner is always re-rolled by the strict kernel, whatever the screening precision
+    assert rel_err(res.best_last, o_best.best_last) <= TOL_F64
+    assert rel_err(res.best_cumulative, o_best.best_cumulative) <= TOL_F64
+    assert res.evaluated == n and res.rollout_steps == n * p.depth * p.n_substeps
+
+
+@pytest.mark.parametrize("prec", [M.PREC_F64, M.PREC_FAST])
+def test_explicit_controls_match_seeded_and_oracle(solver, prec):
+    torch = _torch()
+    p = W.config2_problem()
+    n = 4096
+    rud, thr = W.seeded_controls(W.SEED, 0, n, p.depth, p.last_rudder, p.last_throttle)
+    d_r = torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous()
+    d_t = torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous()
+    last = torch.empty(n, dtype=torch.float64, device="cuda")
+    res = solver.eval_candidates(p, d_r, d_t, n, prec, M.SELECT_LAST_STEP, last, None)
+    o_last, o_cum, o_best = oracle_explicit(p, rud, thr)
+    assert rel_err(last.cpu().numpy(), o_last).max() <= (TOL_F64 if prec == M.PREC_F64 else TOL_FAST)
+    assert res.best_ordinal == o_best.best_index
+    res2, last2, _ = _run_seeded(solver, p, W.SEED, 0, n, prec)
+    assert np.array_equal(last2, last.cpu().numpy())          # same kernel arithmetic, same bits
+    assert res2.best_ordinal == res.best_ordinal
+
+
+def test_winner_trajectory_matches_oracle_rollout(solver):
+    p = W.config3_problem()
+    res, _, _ = _run_seeded(solver, p, W.SEED, 0, 4096, M.PREC_FAST)
+    cfg, veh, cps, sub = oracle_args(p)
+    rud, thr = W.seeded_controls(W.SEED, res.best_ordinal, 1, p.depth, p.last_rudder, p.last_throttle)
+    traj = O.rollout(cfg, veh, cps, p.depth, sub, rud[:, 0], thr[:, 0])
+    got = traj_array(res)
+    for l in range(p.depth + 1):
+        want = [traj[l].v.s.x, traj[l].v.s.y, traj[l].v.s.heading, traj[l].v.s.speed, traj[l].v.rpm]
+        assert rel_err(got[l, :5], want).max() <= TOL_F64, l
+        if l:
+            assert rel_err(got[l, 5:7], [traj[l].v.cmg, traj[l].v.sog]).max() <= 1e-10
+            assert got[l, 7] == traj[l].last_rudder and got[l, 8] == traj[l].last_throttle
+            assert rel_err(got[l, 9], traj[l].score) <= TOL_F64
+    assert res.first_rudder == rud[0, 0] and res.first_throttle == thr[0, 0]
+
+
+def test_cumulative_selection(solver):
+    p = W.config2_problem()
+    n = 4096
+    res, last, cum = _run_seeded(solver, p, W.SEED, 0, n, M.PREC_FAST, M.SELECT_CUMULATIVE)
+    o_last, o_cum, o_best = oracle_seeded(p, W.SEED, 0, n, cumulative=True)
+    assert res.best_ordinal == o_best.best_index
+    assert rel_err(res.best_cumulative, o_best.best_cumulative) <= TOL_F64
+
+
+def test_shard_offsets_and_ragged_sizes(solver):
+    """first_ordinal != 0 (a GPU's shard of a larger set) and sizes that are not multiples of the wave size."""
+    p = W.config2_problem(depth=6)
+    for first, count in [(0, 1), (5, 63), (1000, 65), (123456789, 257)]:
+        res, last, cum = _run_seeded(solver, p, 77, first, count, M.PREC_F64)
+        o_last, o_cum, o_best = oracle_seeded(p, 77, first, count)
+        assert rel_err(last, o_last).max() <= TOL_F64
+        assert res.best_ordinal == o_best.best_index
+
+
+def test_batch_of_problems(solver):
+    probs, seeds = W.fleet_problems(24, depth=8)
+    n = 512
+    res = solver.eval_seeded_batch(probs, seeds, n, M.PREC_FAST)
+    for p, s, r in zip(probs, seeds, res):
+        o_last, o_cum, o_best = oracle_seeded(p, s, 0, n)
+        assert r.best_ordinal == o_best.best_index
+        assert rel_err(r.best_last, o_best.best_last) <= TOL_F64
+
+
+def test_single_rollout_strict_and_fast(solver):
+    """VehicleState::simulate itself through the C-ABI, incl. the reference-native 11-substep level."""
+    p, _plan = W.config1_problem(depth=5, current=(0.3, -0.2))
+    cfg, veh, cps, sub = oracle_args(p)
+    rud = [0.5, -1.0, 0.25, 1.5, 0.0][:p.depth]
+    thr = [0.75, 1.0, 0.0, -0.5, 0.3][:p.depth]
+    traj = O.rollout(cfg, veh, cps, p.depth, sub, rud, thr)
+    for prec, tol in [(M.PREC_F64, TOL_F64), (M.PREC_FAST, 1e-9)]:
+        got = traj_array(solver.rollout(p, rud, thr, prec))
+        for l in range(1, p.depth + 1):
+            want = [traj[l].v.s.x, traj[l].v.s.y, traj[l].v.s.heading, traj[l].v.s.speed, traj[l].v.rpm]
+            assert rel_err(got[l, :5], want).max() <= tol, (prec, l, got[l, :5], want)
+            assert rel_err(got[l, 9], traj[l].score) <= max(tol, 1e-6 if prec == M.PREC_FAST else 0), (prec, l)
