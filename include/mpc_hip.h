@@ -172,6 +172,13 @@ int         mpc_hip_fetch_results(mpc_hip_handle *h, mpc_result *h_results, uint
  * that hold the minimum combines shards. */
 int         mpc_hip_device_winners(mpc_hip_handle *h, uint64_t **d_winners);
 
+/* copy the packed winners (2 uint64 per problem) to caller-owned device memory, on the handle's stream: the
+ * form a host that owns its communicator buffers (torch.distributed / RCCL) uses for the min-allreduce */
+int         mpc_hip_copy_winners(mpc_hip_handle *h, uint64_t *d_dst);
+/* HIP-event times summed over the runs since the last reset (at most the last 1024 runs): kernel_ms_sum covers
+ * the rollout kernel K1 alone, total_ms_sum first launch to last kernel end.  Synchronises the stream. */
+int         mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, double *kernel_ms_sum, double *total_ms_sum);
+
 /* ---- the reference's own candidate set: limited-branching tree (BASELINE config 1) ------------------------
  * Replaces controller.cpp:80-189: iterative-deepening DFS over the control sets of :121-146, evaluated here
  * level-synchronously (children of all nodes of a level in DFS order, so a leaf's index IS its DFS ordinal);

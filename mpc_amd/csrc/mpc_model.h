@@ -4,10 +4,11 @@
  *   strict_*  FP64, the reference's statements in the reference's order (VehicleState.h:111-148,
  *             controller.cpp:231-241).  Built with -ffp-contract=off, IEEE divide/sqrt, ocml libm.
  *   fast_*    FP64 state, algebraically streamlined for the CDNA4 vector ALU (FP64 at half the FP32 rate,
- *             transcendentals at quarter rate): no sin/cos/fmod/divide per substep.
+ *             transcendentals at quarter rate): no sin/cos/fmod/divide per substep, ~36 FP64 instructions.
  *
- * Shared per-problem data lives in LDS (staged once per workgroup by the kernels in mpc_hip.hip):
- *   cp[l*CP_STRIDE + k]   k: 0 x, 1 y, 2 heading, 3 speed, 4 sin(heading), 5 cos(heading)
+ * Shared per-problem data lives in LDS (staged once per workgroup by the kernels):
+ *   cp[l*CP_STRIDE + k]   k: 0 x, 1 y, 2 heading, 3 speed, 4 sin(heading), 5 cos(heading),
+ *                            6 x - cx*T_l, 7 y - cy*T_l   (T_l = time from the start to checkpoint l)
  *   sub[s*SUB_STRIDE + k] k: 0 dt, 1 1000*dt, 2 dt/2000, 3 cx*dt, 4 cy*dt, 5 1/dt
  */
 #ifndef MPC_MODEL_H
@@ -17,7 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#define CP_STRIDE 6
+#define CP_STRIDE 8
 #define SUB_STRIDE 6
 
 namespace mpc {
@@ -121,11 +122,25 @@ __device__ inline double strict_score(const double *cp, const Veh &s, const Weig
 }
 
 /* ========================================= fast ======================================================= */
-/* heading is carried as (sh, ch) = (sin h, cos h); dx, dy are the last substep's displacement */
-struct FastVeh { double x, y, sh, ch, v, rpm, dx, dy; };
+/* Heading is carried as (sh, ch) = (sin h, cos h).  x, y integrate the vessel's motion THROUGH THE WATER only:
+ * the current's contribution sum(cx*dt) is the same for every candidate, so it is taken off the checkpoint on
+ * the host (cp[6], cp[7]) instead of being added to every lane in every substep.  delta is the last substep's
+ * v*dt, from which the last displacement over ground (for course made good / speed over ground) follows. */
+struct FastVeh { double x, y, sh, ch, v, rpm, delta; };
 
-/* sqrt(a) for a >= 0 from the hardware reciprocal-sqrt estimate and one coupled Newton/Goldschmidt step
- * (relative error ~1e-16); a == 0 gives ~1e-154 instead of 0 */
+/* sqrt(a), a >= 0: hardware reciprocal-sqrt estimate + one coupled Newton (Goldschmidt) step, relative error
+ * ~1e-13 or better; a == 0 gives ~1e-154 instead of 0 */
+__device__ inline double fast_sqrt1(double a)
+{
+    a = fmax(a, 1.0e-300);
+    const double y = __builtin_amdgcn_rsq(a);
+    const double g = a * y;
+    const double hh = 0.5 * y;
+    const double r = fma(-hh, g, 0.5);
+    return fma(g, r, g);
+}
+
+/* the same with a residual correction (~1 ulp), for the scoring terms */
 __device__ inline double fast_sqrt(double a)
 {
     a = fmax(a, 1.0e-300);
@@ -134,7 +149,6 @@ __device__ inline double fast_sqrt(double a)
     const double hh = 0.5 * y;
     const double r = fma(-hh, g, 0.5);
     g = fma(g, r, g);
-    /* one more correction step on the residual: keeps the result within ~1 ulp */
     const double e = fma(-g, g, a);
     return fma(e, hh, g);
 }
@@ -149,47 +163,49 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
     const double kpc = PROP_COEFFICIENT * cos_ra;              /* thrust_fwd = kpc * (ps^2 - v^2)        */
     const double kyaw = (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra;   /* yaw_rate = kyaw * rudder_speed */
     constexpr double C_PROP = PROP_RATIO / PROP_PITCH;
+#ifdef MPC_SUBSTEP_UNROLL
+#pragma unroll MPC_SUBSTEP_UNROLL
+#endif
     for (int k = 0; k < n_sub; k++) {
         const double *q = sub + k * SUB_STRIDE;
-        const double dt = q[0], max_step = q[1], dt_over_mass = q[2], cxdt = q[3], cydt = q[4];
-        /* rpm slew: rpm += clamp((target - rpm)/dt, +-1000) * dt */
-        const double step = fmin(fmax(target_rpm - s.rpm, -max_step), max_step);
-        s.rpm += step;
+        const double dt = q[0], max_step = q[1], dt_over_mass = q[2];
+        /* rpm slew: rpm += clamp((target - rpm)/dt, +-1000) * dt  ==  clamp(target, rpm - 1000 dt, rpm + 1000 dt) */
+        s.rpm = fmin(fmax(target_rpm, s.rpm - max_step), s.rpm + max_step);
         const double ps = C_PROP * s.rpm;
-        const double rudder_speed = fmax(fast_sqrt(ps), s.v);
+        const double rudder_speed = fmax(fast_sqrt1(ps), s.v);
         const double v2 = s.v * s.v;
         const double thrust_fwd = kpc * fma(ps, ps, -v2);
         const double force = fma(-DRAG_COEFFICIENT, v2 * s.v, thrust_fwd);
-        /* heading += yaw_rate*dt as a rotation of (sin h, cos h); |dtheta| <= 0.05 rad for dt <= 0.1 s, where
-         * the degree-7/8 Taylor polynomials are exact to the last bit */
-        const double a = (kyaw * rudder_speed) * dt;
+        /* heading += yaw_rate*dt as a rotation of (sin h, cos h); |a| <= 0.05 rad for dt <= 0.1 s, where the
+         * degree-5/6 Taylor polynomials are good to 1.5e-13 absolute (2e-15 at dt = 0.05) */
+        const double a = (kyaw * dt) * rudder_speed;
         const double a2 = a * a;
-        const double sa = a * fma(a2, fma(a2, fma(a2, -1.0 / 5040, 1.0 / 120), -1.0 / 6), 1.0);
-        const double ca = fma(a2, fma(a2, fma(a2, fma(a2, 1.0 / 40320, -1.0 / 720), 1.0 / 24), -0.5), 1.0);
+        const double sa = a * fma(a2, fma(a2, 1.0 / 120, -1.0 / 6), 1.0);
+        const double ca = fma(a2, fma(a2, fma(a2, -1.0 / 720, 1.0 / 24), -0.5), 1.0);
         const double sh = fma(s.sh, ca, s.ch * sa);
         const double ch = fma(s.ch, ca, -(s.sh * sa));
         s.sh = sh; s.ch = ch;
         s.v = fma(force, dt_over_mass, s.v);
-        const double delta = s.v * dt;
-        s.dx = fma(delta, sh, cxdt);
-        s.dy = fma(delta, ch, cydt);
-        s.x += s.dx;
-        s.y += s.dy;
+        s.delta = s.v * dt;
+        s.x = fma(s.delta, sh, s.x);
+        s.y = fma(s.delta, ch, s.y);
     }
 }
 
-/* tracking cost from the fast state; inv_dt_last = 1/dt of the level's last substep */
-__device__ inline double fast_score(const double *cp, const FastVeh &s, const Weights &w, double inv_dt_last)
+/* tracking cost from the fast state; q_last = the schedule row of the level's last substep */
+__device__ inline double fast_score(const double *cp, const FastVeh &s, const Weights &w, const double *q_last)
 {
-    double dx = s.dx, dy = s.dy;
+    /* the last substep's displacement over ground, VehicleState.h:139-140 */
+    const double gdx = fma(s.delta, s.sh, q_last[3]), gdy = fma(s.delta, s.ch, q_last[4]);
+    double dx = gdx, dy = gdy;
     if (dx == 0.0 && dy == 0.0) dx = 1.0;          /* atan2(0, 0) = 0: course made good = pi/2 (east)    */
     /* |headingDifference(ref, cmg)| = |angle between the travel direction and the reference heading| */
     const double cross = dx * cp[5] - dy * cp[4];
     const double dot = fma(dy, cp[5], dx * cp[4]);
     const double heading_diff = (double)fabsf(atan2f((float)cross, (float)dot));
-    const double sog = fast_sqrt(fma(s.dx, s.dx, s.dy * s.dy)) * inv_dt_last;
+    const double sog = fast_sqrt(fma(gdx, gdx, gdy * gdy)) * q_last[5];
     const double speed_diff = fabs(cp[3] - sog);
-    const double ex = cp[0] - s.x, ey = cp[1] - s.y;
+    const double ex = cp[6] - s.x, ey = cp[7] - s.y;
     const double d = exp(fast_sqrt(fma(ex, ex, ey * ey)));
     return fma(w.wd, d, fma(w.wh, heading_diff, w.ws * speed_diff));
 }

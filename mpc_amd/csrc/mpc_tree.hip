@@ -1,0 +1,382 @@
+/*
+ * mpc_tree.hip -- the reference's own candidate set: the limited-branching tree of controller.cpp:80-189.
+ *
+ * The reference walks the tree depth-first, once per deepening iteration, with an explicit stack.  Here the
+ * tree is expanded level-synchronously.  The children of all nodes of a level are laid out in parent order and,
+ * within a parent, throttle-outer / rudder-inner (controller.cpp:174-182), so a node's index within its level
+ * IS the ordinal at which the reference's DFS of that depth visits it.  Iteration `it` of the reference
+ * (controller.cpp:80) selects, among the leaves at depth it+1, the first one with the strictly smallest
+ * LAST-step score (:158-166): that is the (score, index) argmin of level it+1 here, so one expansion yields
+ * every deepening iteration's result.  The deadline of :101-103 is polled between levels; a level that does
+ * not complete before end_time is discarded exactly as the reference discards an unfinished iteration.
+ *
+ * Kernels per level:  count_kernel (children per node, control sets of :121-146) -> 3-kernel exclusive scan
+ * -> expand_kernel (one lane per child: parent lookup by binary search, strict FP64 simulate + score, SoA store,
+ * wavefront/LDS argmin) -> level_reduce_kernel.  After the last level trace_kernel walks the parent links (one tiny launch per level).
+ */
+#include <math.h>
+#include <string.h>
+
+#include "mpc_internal.h"
+
+using namespace mpc;
+
+/* ---- control sets, controller.cpp:121-146 --------------------------------------------------------------- */
+struct ControlSet { double r[6], t[5]; int nr, nt; };
+
+__device__ inline void control_set(const DevProblem &P, double last_r, double last_t, ControlSet &c)
+{
+    const double tol = P.tol;
+    int nr = 0, nt = 0;
+    c.r[nr++] = P.minr; c.r[nr++] = P.midr; c.r[nr++] = P.maxr;
+    c.t[nt++] = P.mint; c.t[nt++] = P.maxt;
+    const double low_r = last_r - P.gr, high_r = last_r + P.gr;
+    if (P.minr + tol < low_r && fabs(P.midr - low_r) > tol) c.r[nr++] = low_r;
+    if (fabs(P.midr - high_r) > tol && P.maxr > high_r + tol) c.r[nr++] = high_r;
+    if (fabs(P.minr - last_r) > tol && fabs(P.midr - last_r) > tol && fabs(P.maxr - last_r) > tol) c.r[nr++] = last_r;
+    const double low_t = last_t - P.gt, high_t = last_t + P.gt;
+    if (P.mint + tol < low_t) c.t[nt++] = low_t;
+    if (P.maxt > high_t + tol) c.t[nt++] = high_t;
+    if (fabs(P.mint - last_t) > tol && fabs(P.maxt - last_t) > tol) c.t[nt++] = last_t;
+    c.nr = nr; c.nt = nt;
+}
+
+/* only the counts (same predicates) */
+__device__ inline uint32_t control_count(const DevProblem &P, double last_r, double last_t)
+{
+    const double tol = P.tol;
+    int nr = 3, nt = 2;
+    const double low_r = last_r - P.gr, high_r = last_r + P.gr;
+    nr += (P.minr + tol < low_r && fabs(P.midr - low_r) > tol);
+    nr += (fabs(P.midr - high_r) > tol && P.maxr > high_r + tol);
+    nr += (fabs(P.minr - last_r) > tol && fabs(P.midr - last_r) > tol && fabs(P.maxr - last_r) > tol);
+    const double low_t = last_t - P.gt, high_t = last_t + P.gt;
+    nt += (P.mint + tol < low_t);
+    nt += (P.maxt > high_t + tol);
+    nt += (fabs(P.mint - last_t) > tol && fabs(P.maxt - last_t) > tol);
+    return (uint32_t)(nr * nt);
+}
+
+struct LevelPtrs {
+    double *x, *y, *h, *v, *rpm, *cmg, *sog, *last_r, *last_t, *cum, *last_score;
+    uint32_t *parent, *count, *offset;
+};
+
+static LevelPtrs ptrs(const TreeLevelBuf &b)
+{
+    return LevelPtrs{b.x, b.y, b.h, b.v, b.rpm, b.cmg, b.sog, b.last_r, b.last_t, b.cum, b.last_score,
+                     b.parent, b.count, b.offset};
+}
+
+__global__ void root_kernel(const DevProblem *__restrict__ probs, LevelPtrs L)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const DevProblem &P = probs[0];
+    L.x[0] = P.sx; L.y[0] = P.sy; L.h[0] = P.sh; L.v[0] = P.sv; L.rpm[0] = P.srpm;
+    L.cmg[0] = 0; L.sog[0] = 0; L.last_r[0] = P.last_r; L.last_t[0] = P.last_t; L.cum[0] = 0; L.last_score[0] = 0;
+    L.parent[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void count_kernel(const DevProblem *__restrict__ probs, LevelPtrs L, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) L.count[i] = control_count(probs[0], L.last_r[i], L.last_t[i]);
+}
+
+/* ---- exclusive scan of uint32 counts: per-block sums, scan of the sums, per-block rescan ----------------- */
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *sh, uint32_t &total)
+{
+    /* Hillis-Steele over 256 threads in LDS */
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
+        const uint32_t a = (t >= d) ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += a;
+        __syncthreads();
+    }
+    total = sh[SCAN_BLOCK - 1];
+    const uint32_t ex = sh[t] - v;
+    __syncthreads();
+    return ex;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(const uint32_t *__restrict__ in, uint32_t n,
+                                                               uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) s += in[base + j];
+    uint32_t total;
+    block_exclusive_scan(s, sh, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+/* one block: exclusive scan of the tile sums in place; sums[nt] = grand total (as two words: lo, overflow flag) */
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_top_kernel(uint32_t *__restrict__ sums, uint32_t nt)
+{
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nt; base += SCAN_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nt ? sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, sh, total);
+        const unsigned long long c = carry;
+        if (i < nt) sums[i] = (uint32_t)(c + ex);
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[nt] = (uint32_t)(carry & 0xFFFFFFFFull);
+        sums[nt + 1] = (uint32_t)(carry >> 32);          /* non-zero: the level does not fit 32-bit indices */
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
+                                                                const uint32_t *__restrict__ sums,
+                                                                uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], s = 0;
+    for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? in[base + j] : 0; s += v[j]; }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(s, sh, total) + sums[blockIdx.x];
+    for (int j = 0; j < SCAN_ITEMS; j++) { if (base + j < n) out[base + j] = run; run += v[j]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = sums[gridDim.x];
+}
+
+/* ---- expansion: one lane per child ------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
+                                                     LevelPtrs B, uint32_t n_child, int level,
+                                                     uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord)
+{
+    __shared__ double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ uint64_t red[8];
+    const DevProblem &P = probs[0];
+    double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    stage_problem(P, cpL, subL);
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t k = ~0ull, o = ~0ull;
+    if (c < n_child) {
+        /* parent = last node whose offset <= c */
+        uint32_t lo = 0, hi = n_parent;                 /* invariant: offset[lo] <= c < offset[hi] */
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (A.offset[mid] <= c) lo = mid; else hi = mid;
+        }
+        const uint32_t par = lo, j = c - A.offset[par];
+        ControlSet cs;
+        const double plr = A.last_r[par], plt = A.last_t[par];
+        control_set(P, plr, plt, cs);
+        const int ti = (int)(j / (uint32_t)cs.nr), ri = (int)(j % (uint32_t)cs.nr);   /* throttle outer, rudder inner */
+        double r = cs.r[0], t = cs.t[0];
+#pragma unroll
+        for (int q = 1; q < 6; q++) if (q == ri) r = cs.r[q];
+#pragma unroll
+        for (int q = 1; q < 5; q++) if (q == ti) t = cs.t[q];
+        Veh s{A.x[par], A.y[par], A.h[par], A.v[par], A.rpm[par], 0.0, 0.0};
+        strict_level(s, r, t, subL, P.nsub, P.cx, P.cy);                              /* controller.cpp:149-150 */
+        const Weights w{P.wd, P.wh, P.ws};
+        const double score = strict_score(cpL + level * CP_STRIDE, s, w);             /* :155 */
+        B.x[c] = s.x; B.y[c] = s.y; B.h[c] = s.h; B.v[c] = s.v; B.rpm[c] = s.rpm; B.cmg[c] = s.cmg; B.sog[c] = s.sog;
+        B.last_r[c] = r; B.last_t[c] = t;                                             /* :152-153 (unclamped) */
+        B.cum[c] = A.cum[par] + score;                                                /* :156 */
+        B.last_score[c] = score;
+        B.parent[c] = par;
+        k = key_of(score); o = c;
+    }
+    block_argmin(k, o, red);
+    if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; }
+}
+
+__global__ __launch_bounds__(256) void level_reduce_kernel(const uint64_t *__restrict__ pkey,
+                                                           const uint64_t *__restrict__ pord, uint32_t nblk,
+                                                           LevelPtrs B, uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t red[8];
+    uint64_t k = ~0ull, o = ~0ull;
+    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
+    block_argmin(k, o, red);
+    if (threadIdx.x == 0) {
+        out[0] = k; out[1] = o;
+        out[2] = (o != ~0ull) ? (uint64_t)__double_as_longlong(B.cum[o]) : KEY_INF;
+        out[3] = (o != ~0ull) ? (uint64_t)__double_as_longlong(B.last_score[o]) : KEY_INF;
+    }
+}
+
+/* one launch per level, leaf to root: the cursor (a device word) carries the node index up the parent links */
+__global__ void trace_kernel(LevelPtrs L, int l, int depth, uint32_t leaf, uint32_t *__restrict__ cursor,
+                             DevResult *__restrict__ results)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    DevResult &R = results[0];
+    const uint32_t i = (l == depth) ? leaf : *cursor;
+    R.traj[l] = mpc_level_state{L.x[i], L.y[i], L.h[i], L.v[i], L.rpm[i], L.cmg[i], L.sog[i],
+                                L.last_r[i], L.last_t[i], L.cum[i]};
+    if (l == depth) {
+        R.best_last = L.last_score[i]; R.best_cum = L.cum[i]; R.key_bits = key_of(L.last_score[i]);
+        R.ordinal = leaf; R.refined = 0; R.overflow = 0;
+    }
+    *cursor = L.parent[i];
+}
+
+/* ---- host ------------------------------------------------------------------------------------------------------ */
+static void free_level(TreeLevelBuf &b)
+{
+    (void)hipFree(b.x); (void)hipFree(b.y); (void)hipFree(b.h); (void)hipFree(b.v); (void)hipFree(b.rpm);
+    (void)hipFree(b.cmg); (void)hipFree(b.sog); (void)hipFree(b.last_r); (void)hipFree(b.last_t); (void)hipFree(b.cum);
+    (void)hipFree(b.last_score); (void)hipFree(b.parent); (void)hipFree(b.count); (void)hipFree(b.offset);
+    b = TreeLevelBuf();
+}
+
+void mpc_tree_free(mpc_hip_handle *h)
+{
+    for (auto &b : h->tree) free_level(b);
+    h->tree.clear();
+    (void)hipFree(h->d_scan_tmp); h->d_scan_tmp = nullptr; h->cap_scan_tmp = 0;
+}
+
+static int ensure_level(mpc_hip_handle *h, TreeLevelBuf &b, size_t n)
+{
+    if (n <= b.cap) return MPC_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    free_level(b);
+    size_t cap = 1024;
+    while (cap < n) cap <<= 1;
+    if (cap > n + n / 4 && n > (1u << 20)) cap = n + n / 8;      /* large levels: little slack */
+    double **dbl[] = {&b.x, &b.y, &b.h, &b.v, &b.rpm, &b.cmg, &b.sog, &b.last_r, &b.last_t, &b.cum, &b.last_score};
+    for (double **p : dbl) HIP_TRY(hipMalloc(p, sizeof(double) * cap));
+    HIP_TRY(hipMalloc(&b.parent, sizeof(uint32_t) * cap));
+    HIP_TRY(hipMalloc(&b.count, sizeof(uint32_t) * cap));
+    HIP_TRY(hipMalloc(&b.offset, sizeof(uint32_t) * (cap + 1)));
+    b.cap = cap;
+    return MPC_OK;
+}
+
+extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
+                                  mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
+                                  mpc_tree_level *h_level_best, mpc_result *h_result)
+{
+    if (!h || !h_problem || !h_result) { mpc_set_err("solve_tree: NULL argument"); return MPC_ERR_INVALID; }
+    if (precision != MPC_PREC_F64) {
+        mpc_set_err("solve_tree evaluates with MPC_PREC_F64 (the reference's arithmetic) only");
+        return MPC_ERR_INVALID;
+    }
+    if (int s = mpc_check_problem(h_problem, precision)) return s;
+    if (max_levels > h_problem->depth) { mpc_set_err("solve_tree: max_levels exceeds the checkpoints supplied"); return MPC_ERR_INVALID; }
+    if (int s = mpc_use_device(h)) return s;
+    memset(h_result, 0, sizeof *h_result);
+    if (max_levels <= 0) {                        /* controller.cpp:80 never entered -> :196 */
+        h_result->status = MPC_ERR_NO_ITERATION;
+        return MPC_ERR_NO_ITERATION;
+    }
+    if (max_nodes == 0) max_nodes = 1ull << 28;
+    if (max_nodes > 0xFFFFFFF0ull) max_nodes = 0xFFFFFFF0ull;
+    if (int s = mpc_hip_upload_problems(h, h_problem, nullptr, 1)) return s;
+    if ((int)h->tree.size() < max_levels + 1) h->tree.resize(max_levels + 1);
+
+    hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
+    HIP_TRY(hipEventRecord(ev[0], h->stream));
+    HIP_TRY(hipEventRecord(ev[1], h->stream));
+    if (int s = ensure_level(h, h->tree[0], 1)) return s;
+    h->tree[0].n = 1;
+    hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]));
+    HIP_TRY(hipGetLastError());
+
+    int completed = 0;
+    uint64_t best_leaf = 0, steps = 0, evaluated = 0;
+    for (int it = 0; it < max_levels; it++) {
+        if (now && now(now_ctx) >= end_time) break;                       /* controller.cpp:101-103 */
+        TreeLevelBuf &A = h->tree[it];
+        const uint32_t n = (uint32_t)A.n;
+        /* children per node and their offsets */
+        const uint32_t ntile = (n + SCAN_TILE - 1) / SCAN_TILE;
+        if ((size_t)ntile + 2 > h->cap_scan_tmp) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_scan_tmp); h->d_scan_tmp = nullptr;
+            HIP_TRY(hipMalloc(&h->d_scan_tmp, sizeof(uint32_t) * ((size_t)ntile + 2) * 2));
+            h->cap_scan_tmp = ((size_t)ntile + 2) * 2;
+        }
+        hipLaunchKernelGGL(count_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, A.count, n, h->d_scan_tmp);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->d_scan_tmp, ntile);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, A.count, n, h->d_scan_tmp, A.offset);
+        HIP_TRY(hipGetLastError());
+        uint32_t tot[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_scan_tmp + ntile, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(tot, h->h_pair, sizeof tot);
+        if (tot[1] != 0 || tot[0] > max_nodes) break;                     /* does not fit: stop like a deadline */
+        const uint32_t nchild = tot[0];
+        TreeLevelBuf &B = h->tree[it + 1];
+        if (int s = ensure_level(h, B, nchild)) {
+            if (s == MPC_ERR_HIP) { (void)hipGetLastError(); break; }     /* out of memory: stop like a deadline */
+            return s;
+        }
+        B.n = nchild;
+        const uint32_t nblk = (nchild + 255) / 256;
+        if (int s = mpc_ensure_partials(h, nblk)) return s;
+        hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), nchild, it,
+                           h->d_pkey, h->d_pord);
+        hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, ptrs(B),
+                           h->d_winners);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
+        completed = it + 1;
+        best_leaf = h->h_pair[1];
+        evaluated += nchild;
+        steps += (uint64_t)nchild * (uint64_t)h_problem->n_substeps;
+        if (h_level_best) {
+            h_level_best[it].n_leaves = nchild;
+            h_level_best[it].best_leaf = h->h_pair[1];
+            memcpy(&h_level_best[it].best_score, &h->h_pair[3], sizeof(double));
+            memcpy(&h_level_best[it].best_cumulative, &h->h_pair[2], sizeof(double));
+        }
+    }
+    HIP_TRY(hipEventRecord(ev[2], h->stream));
+    if (completed == 0) {
+        HIP_TRY(hipEventRecord(ev[3], h->stream));
+        h->runs++;
+        h_result->status = MPC_ERR_NO_ITERATION;                          /* controller.cpp:196 */
+        return MPC_ERR_NO_ITERATION;
+    }
+    for (int l = completed; l >= 0; l--)
+        hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(h->tree[l]), l, completed,
+                           (uint32_t)best_leaf, h->d_list_count, h->d_results);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[3], h->stream));
+    h->runs++;
+    HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results, sizeof(DevResult), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const DevResult &R = h->h_results[0];
+    float k1 = 0, total = 0;
+    (void)hipEventElapsedTime(&k1, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&total, ev[0], ev[3]);
+    h_result->levels = completed;
+    h_result->best_ordinal = R.ordinal;
+    h_result->best_last = R.best_last; h_result->best_cumulative = R.best_cum;
+    h_result->first_rudder = R.traj[1].rudder; h_result->first_throttle = R.traj[1].throttle;
+    h_result->evaluated = evaluated; h_result->rollout_steps = steps;
+    h_result->kernel_ms = k1; h_result->total_ms = total;
+    memcpy(h_result->trajectory, R.traj, sizeof(mpc_level_state) * (size_t)(completed + 1));
+    h_result->status = MPC_OK;
+    if (!isfinite(h_result->first_rudder) || !isfinite(h_result->first_throttle)) {
+        h_result->status = MPC_ERR_NON_FINITE;                            /* controller.cpp:201-202 */
+        return MPC_ERR_NON_FINITE;
+    }
+    h->ran = false;
+    return MPC_OK;
+}

@@ -1,0 +1,131 @@
+"""GPU parity of the reference-native limited-branching tree search (controller.cpp:80-189) against the oracle's
+DFS restatement: per deepening iteration the leaf count, the DFS ordinal of the chosen leaf and its scores, and
+the returned trajectory / first control.  Scenarios follow the reference's test_controller.cpp: the LRL
+semicircle of updateReferenceTrajectoryTest (:449-467) and the go-straight / turn scenarios of the
+commented-out tests (:44-267)."""
+import math
+
+import numpy as np
+import pytest
+
+import mpc_amd as M
+from mpc_amd import workloads as W
+from helpers import oracle_args, rel_err, traj_array
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _oracle_tree(p, max_levels, budget=-1):
+    cfg, veh, cps, sub = oracle_args(p)
+    start = O.State(p.start_x, p.start_y, p.start_heading, p.start_speed, 0.0)
+    return O.mpc_tree(cfg, start, cps, max_levels, budget)
+
+
+def _check(solver, p, max_levels):
+    res, levels = solver.solve_tree(p, max_levels)
+    it, traj, olev, nodes = _oracle_tree(p, max_levels)
+    assert res.status == 0 and res.levels == it == max_levels
+    for l in range(it):
+        assert levels[l].n_leaves == olev[l].n_leaves, l
+        assert levels[l].best_leaf == olev[l].best_leaf, l
+        assert rel_err(levels[l].best_score, olev[l].best_score) <= TOL
+        assert rel_err(levels[l].best_cumulative, olev[l].best_cumulative) <= TOL
+    got = traj_array(res)
+    for l in range(it + 1):
+        want = [traj[l].v.s.x, traj[l].v.s.y, traj[l].v.s.heading, traj[l].v.s.speed, traj[l].v.rpm]
+        assert rel_err(got[l, :5], want).max() <= TOL, l
+        assert got[l, 7] == traj[l].last_rudder and got[l, 8] == traj[l].last_throttle, l
+        assert rel_err(got[l, 9], traj[l].score) <= TOL
+        if l:
+            assert rel_err(got[l, 5:7], [traj[l].v.cmg, traj[l].v.sog]).max() <= 1e-10
+    assert res.first_rudder == traj[1].last_rudder and res.first_throttle == traj[1].last_throttle
+    assert res.evaluated == sum(olev[l].n_leaves for l in range(it))
+    return res
+
+
+def _semicircle(length_s, current=(0.2, -0.1), weights=(1.0, 20.0, 5.0)):
+    """test_controller.cpp:449-467: LRL, rho 8, v 2.5, start t = 4, truncated to length_s seconds of plan."""
+    w = W.DubinsWrapper((0.0, 0.0, math.pi / 2), (0.0, math.pi, 0.0), 8.0, W.LRL, 2.5, 4.0)
+    w.end_time = 4.0 + length_s
+    plan = W.DubinsPlan([w])
+    depth = plan.max_iterations(4.0)
+    return M.make_problem((0.0, 0.0, 0.0, 2.5), plan.checkpoints(4.0, depth), M.substep_schedule(1.0),
+                          last=(0.0, 0.0), current=current, weights=weights), depth
+
+
+@pytest.mark.parametrize("length_s", [3.5, 4.5, 5.5])
+def test_semicircle_matches_oracle_and_survey_probe(solver, length_s):
+    p, depth = _semicircle(length_s)
+    assert depth == int(length_s - 1)
+    res = _check(solver, p, depth)
+    # SURVEY.md section 8c probe of the compiled reference: the chosen first control
+    want = {3.5: (0.0625, 1.0), 4.5: (-0.0625, 1.0), 5.5: (-0.0625, 1.0)}[length_s]
+    assert (res.first_rudder, res.first_throttle) == want
+
+
+def test_semicircle_reference_test_weights(solver):
+    """updateConfig(0.0625, 0.125, 1, 1, 0, ...) of test_controller.cpp:455"""
+    p, depth = _semicircle(5.5, current=(0.0, 0.0), weights=(1.0, 1.0, 0.0))
+    _check(solver, p, depth)
+
+
+@pytest.mark.parametrize("depth", [3, 4, 5])
+def test_config1_straight_line(solver, depth):
+    p, plan = W.config1_problem(depth=depth)
+    res = _check(solver, p, depth)
+    if depth <= 4:
+        assert res.first_rudder == 0.0          # on the line, heading along it: no rudder
+    # at depth 5 the reference itself picks rudder 1.0: only the LAST level's score is compared
+    # (controller.cpp:158-166), and _check has shown the GPU makes the same choice
+
+
+@pytest.mark.parametrize("name,start,last", [
+    ("north_from_rest", (0.0, 0.0, 0.0, 0.0), (0.0, 0.0)),
+    ("east_start_north", (0.0, 0.0, math.pi / 2, 2.0), (0.5, 0.75)),
+    ("turn_around", (0.0, 0.0, math.pi, 2.5), (-0.3125, 0.625)),
+    ("offset_last_near_bounds", (3.0, -2.0, 0.2, 1.5), (0.96875, 0.0625)),
+])
+def test_scenarios(solver, name, start, last):
+    # reference heading north along x = 0 from (0, 0), 2.5 m/s: LSL with only the straight segment
+    plan = W.DubinsPlan([W.DubinsWrapper((0.0, 0.0, math.pi / 2), (0.0, 5.0, 0.0), 8.0, W.LSL, 2.5, 10.0)])
+    depth = 4
+    p = M.make_problem(start, plan.checkpoints(10.0, depth), M.substep_schedule(1.0), last=last, current=(0.1, 0.05))
+    _check(solver, p, depth)
+
+
+def test_self_generated_reference_is_recovered(solver):
+    """realStateTest (test_controller.cpp:174-209): the reference is the model's own response to a constant
+    control; MPC must pick a first control that reproduces it."""
+    cfg = O.default_config()
+    v = O.vehicle(0, 0, 0, 2.0, 0.0)
+    cps = []
+    for i in range(4):
+        v = O.simulate(v, 0.0625, 0.875, 1.0)
+        cps.append((v.s.x, v.s.y, v.s.heading, v.s.speed))
+    p = M.make_problem((0, 0, 0, 2.0), cps, M.substep_schedule(1.0), last=(0.0625, 0.875))
+    res = _check(solver, p, 4)
+    assert (res.first_rudder, res.first_throttle) == (0.0625, 0.875)
+
+
+def test_deadline_and_node_budget(solver):
+    p, depth = _semicircle(6.5)
+    # frozen clock already past the deadline: no iteration completes -> controller.cpp:196
+    with pytest.raises(M.MpcError) as e:
+        solver.solve_tree(p, depth, now=lambda: 10.0, end_time=5.0)
+    assert e.value.status == 5 and "failed to complete a single iteration" in str(e.value)
+    # the clock passes the deadline after a fixed number of polls: the deepest COMPLETED level is returned
+    calls = {"n": 0}
+
+    def clock():
+        calls["n"] += 1
+        return 0.0 if calls["n"] <= 4 else 100.0            # polls: before/after level 0, before/after level 1
+    res, levels = solver.solve_tree(p, depth, now=clock, end_time=50.0)
+    assert res.levels == 2
+    it, traj, olev, nodes = _oracle_tree(p, 2)
+    assert levels[1].best_leaf == olev[1].best_leaf
+    assert res.first_rudder == traj[1].last_rudder and res.first_throttle == traj[1].last_throttle
+    # a level wider than max_nodes ends the search the same way
+    res, levels = solver.solve_tree(p, depth, max_nodes=1000)
+    assert res.levels == 2                                   # level 3 has 3745 leaves
