@@ -64,8 +64,9 @@ def main():
     import torch.distributed as dist
     import mpc_amd as M
     from mpc_amd import workloads as W
+    from mpc_amd.distributed import combine_winners
 
-    rank = int(os.environ.get("RANK", "0"))
+    rank =int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -90,7 +91,6 @@ def main():
         d_last = torch.empty(N_CAND, dtype=torch.float64, device="cuda")
         d_cum = torch.empty(N_CAND, dtype=torch.float64, device="cuda")
         win = torch.zeros(2, dtype=torch.int64, device="cuda")
-        i64max = torch.full((1,), np.iinfo(np.int64).max, dtype=torch.int64, device="cuda")
         solver.upload([problem], [W.SEED])
 
         def step():
@@ -98,11 +98,7 @@ def main():
             if world > 1:
                 # non-negative doubles order like their bit patterns: min score, then min ordinal among the holders
                 solver.copy_winners(win)
-                key = win[0:1].clone()
-                dist.all_reduce(key, op=dist.ReduceOp.MIN)
-                cand = torch.where(win[0:1] == key, win[1:2] + first, i64max)
-                dist.all_reduce(cand, op=dist.ReduceOp.MIN)
-                return key, cand
+                return combine_winners(win, ordinal_offset=first)
             return None
 
         for _ in range(args.warmup):

@@ -14,9 +14,9 @@ _LIB_PATH = os.path.join(_HERE, "libmpc_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "mpc_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libmpc_oracle.so"])
+    if force and os.path.exists(_LIB_PATH):
+        os.remove(_LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libmpc_oracle.so"])   # no-op when up to date
     return _LIB_PATH
 
 
@@ -68,8 +68,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
-        build()
+    try:
+        build()                      # no-op when libmpc_oracle.so is newer than its sources
+    except Exception:
+        if not os.path.exists(_LIB_PATH):
+            raise
     L = C.CDLL(_LIB_PATH)
     dp = C.POINTER(C.c_double)
     L.orc_default_config.argtypes = [C.POINTER(Config)]
@@ -97,7 +100,9 @@ def lib():
                                   C.POINTER(Best)]
     L.orc_rollout.argtypes = [C.POINTER(Config), Vehicle, C.POINTER(State), C.c_int, dp, C.c_int, dp, dp,
                               C.POINTER(MpcState)]
-    L.orc_current_estimate.argtypes = [C.POINTER(HistoryEntry), C.c_int, C.c_int, State, dp, dp]
+    L.orc_seeded_control.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, dp, dp]
+    L.orc_seeded_hash.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]; L.orc_seeded_hash.restype = C.c_uint64
+    L.orc_current_estimate.argtypes =[C.POINTER(HistoryEntry), C.c_int, C.c_int, State, dp, dp]
     _lib = L
     return L
 

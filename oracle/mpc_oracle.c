@@ -405,6 +405,18 @@ void orc_rollout(const orc_config *cfg, orc_vehicle start, const orc_state *chec
     roll_one(cfg, start, checkpoints, depth, substeps, n_substeps, rudders, throttles, 1, &last, &cum, trajectory);
 }
 
+/* the seeded workload definition of include/mpc_candidates.h, exported for the tests */
+void orc_seeded_control(uint64_t seed, uint64_t ordinal, uint32_t level, double last_rudder, double last_throttle,
+                        double *rudder, double *throttle)
+{
+    mpc_candidate_control(seed, ordinal, level, last_rudder, last_throttle, rudder, throttle);
+}
+
+uint64_t orc_seeded_hash(uint64_t seed, uint64_t ordinal, uint32_t level)
+{
+    return mpc_candidate_hash(seed, ordinal, level);
+}
+
 /* ---- CurrentEstimator::getCurrent, CurrentEstimator.cpp:15-41 ------------------------------------- */
 void orc_current_estimate(const orc_history_entry *hist, int n, int enabled, orc_state actual,
                           double *cx, double *cy)

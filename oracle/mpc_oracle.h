@@ -120,6 +120,10 @@ void   orc_rollout(const orc_config *cfg, orc_vehicle start, const orc_state *ch
                    int depth, const double *substeps, int n_substeps,
                    const double *rudders, const double *throttles, orc_mpc_state *trajectory);
 
+void   orc_seeded_control(uint64_t seed, uint64_t ordinal, uint32_t level, double last_rudder,
+                          double last_throttle, double *rudder, double *throttle);
+uint64_t orc_seeded_hash(uint64_t seed, uint64_t ordinal, uint32_t level);
+
 /* CurrentEstimator.cpp restated.  history entries are (state, rudder, throttle). */
 typedef struct { orc_state s; double rudder, throttle; } orc_history_entry;
 void   orc_current_estimate(const orc_history_entry *hist, int n, int enabled, orc_state actual,
