@@ -14,7 +14,12 @@
 #ifndef MPC_MODEL_H
 #define MPC_MODEL_H
 
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define MPC_MODEL_FN __host__ __device__
+#else
+#define MPC_MODEL_FN                      /* host-only build (g++): the strict model is shared with mpc_amd/host */
+#endif
 #include <math.h>
 #include <stdint.h>
 
@@ -50,7 +55,7 @@ struct Weights { double wd, wh, ws; };
 struct Veh { double x, y, h, v, rpm, cmg, sog; };
 
 /* VehicleState.h:20-22 */
-__host__ __device__ inline double rpm_from_speed(double speed)
+MPC_MODEL_FN inline double rpm_from_speed(double speed)
 {
     return IDLE_RPM + (speed / MAX_SPEED) * (MAX_RPM - IDLE_RPM);
 }
@@ -58,7 +63,7 @@ __host__ __device__ inline double rpm_from_speed(double speed)
 /* One level: simulate()'s clamps (VehicleState.h:44-47) and n_sub estimate() calls (:111-148).
  * sin/cos of the rudder angle are loop invariant and cmg/sog are overwritten by every substep, so they are
  * evaluated once / for the last substep only: the values are the ones the reference ends the level with. */
-__device__ inline void strict_level(Veh &s, double rudder, double throttle, const double *sub, int n_sub,
+MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, const double *sub, int n_sub,
                                     double cx, double cy)
 {
     if (rudder < -1) rudder = -1; else if (rudder > 1) rudder = 1;
@@ -105,13 +110,13 @@ __device__ inline void strict_level(Veh &s, double rudder, double throttle, cons
 }
 
 /* path_planner_common State::headingDifference as SURVEY.md section 8c defines it (external; unpinned) */
-__device__ inline double heading_difference(double heading, double other)
+MPC_MODEL_FN inline double heading_difference(double heading, double other)
 {
     return fmod(fmod(other - heading, TWO_PI) + THREE_PI, TWO_PI) - PI;
 }
 
 /* controller.cpp:231-241 */
-__device__ inline double strict_score(const double *cp, const Veh &s, const Weights &w)
+MPC_MODEL_FN inline double strict_score(const double *cp, const Veh &s, const Weights &w)
 {
     const double heading_diff = fabs(heading_difference(cp[2], s.cmg));
     const double speed_diff = fabs(cp[3] - s.sog);
@@ -121,7 +126,8 @@ __device__ inline double strict_score(const double *cp, const Veh &s, const Weig
     return w.wd * d + w.wh * heading_diff + w.ws * speed_diff;
 }
 
-/* ========================================= fast ======================================================= */
+#if defined(__HIPCC__)
+/* ========================================= fast (device only) ========================================== */
 /* Heading is carried as (sh, ch) = (sin h, cos h).  x, y integrate the vessel's motion THROUGH THE WATER only:
  * the current's contribution sum(cx*dt) is the same for every candidate, so it is taken off the checkpoint on
  * the host (cp[6], cp[7]) instead of being added to every lane in every substep.  delta is the last substep's
@@ -209,6 +215,8 @@ __device__ inline double fast_score(const double *cp, const FastVeh &s, const We
     const double d = exp(fast_sqrt(fma(ex, ex, ey * ey)));
     return fma(w.wd, d, fma(w.wh, heading_diff, w.ws * speed_diff));
 }
+
+#endif /* __HIPCC__ */
 
 }  // namespace mpc
 #endif

@@ -1,0 +1,259 @@
+/*
+ * host_tests.cpp -- gtest-free runner for the host-side mirror (gtest is not in the image).  The cases follow the
+ * reference's live tests (test/test_controller.cpp: headingTowardsTest :13-23, currentEstimatorTest1 :384-394,
+ * estimateTest0/1/2 :396-433, updateReferenceTrajectoryTest :449-479) and check the host classes against the CPU
+ * oracle (oracle/mpc_oracle.h: test infrastructure, linked into this TEST binary only).
+ *
+ *   host_tests cpu     no device needed
+ *   host_tests gpu     Controller::mpc / updateReferenceTrajectory through libmpc_hip.so on the GPU
+ */
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "NodeStub.h"
+#include "../../oracle/mpc_oracle.h"
+#include "../../include/mpc_hip.h"
+
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond)                                                                                  \
+    do { g_checks++; if (!(cond)) { g_failed++; std::fprintf(stderr, "FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond); } } while (0)
+#define CHECK_NEAR(a, b, tol) CHECK(std::fabs((a) - (b)) <= (tol))
+
+static long long ulps(double a, double b)
+{
+    long long ia, ib;
+    std::memcpy(&ia, &a, 8); std::memcpy(&ib, &b, 8);
+    return ia > ib ? ia - ib : ib - ia;
+}
+
+static orc_state to_orc(const State& s) { return orc_state{s.x(), s.y(), s.heading(), s.speed(), s.time()}; }
+
+/* ---- CPU ----------------------------------------------------------------------------------------------------- */
+static void headingTowardsTest()
+{
+    State s1(0, 0, 0, 0, 0), north(0, 1, 0, 0, 0), east(1, 0, 0, 0, 0), south(0, -1, 0, 0, 0), west(-1, 0, 0, 0, 0);
+    CHECK_NEAR(s1.headingTo(north), 0, 1e-12);
+    CHECK_NEAR(s1.headingTo(east), M_PI / 2, 1e-12);
+    CHECK_NEAR(s1.headingTo(south), M_PI, 1e-12);
+    CHECK_NEAR(s1.headingTo(west), 3 * M_PI / 2, 1e-12);
+}
+
+static void vehicleStateMatchesOracleBitForBit()
+{
+    /* the reference-run golden vector of SURVEY.md section 4 */
+    VehicleState v(State(10, -5, 1.25, 2.0, 100));
+    VehicleState r = v.simulate(0.5, 0.75, 1.0, std::make_pair(0.3, -0.2));
+    CHECK(r.state.x() == 12.361913597579116 && r.state.y() == -4.7866410095042875);
+    CHECK(r.state.heading() == 1.471070251202069 && r.state.speed() == 2.1681194741262995 && r.rpm == 2400);
+    CHECK(r.courseMadeGood == 1.5643423697798238 && r.speedOverGround == 2.4573982973073774);
+    CHECK(r.state.time() == 100.99999999999994);
+    CHECK(v.state.x() == 10 && v.state.time() == 100);                       /* simulate() does not mutate */
+    /* and a sweep against the oracle */
+    for (int i = 0; i < 200; i++) {
+        const double rud = -1.2 + 0.013 * i, thr = -0.1 + 0.006 * i, t = 0.03 * (i % 70) + 0.01;
+        State s(3.0 * i, -2.0 * i, std::fmod(0.37 * i, 2 * M_PI), 0.014 * i, 50.0 + i);
+        VehicleState a = VehicleState(s).simulate(rud, thr, t, std::make_pair(0.01 * (i % 9), -0.02 * (i % 5)));
+        orc_vehicle ov = orc_vehicle_from_state(to_orc(s));
+        orc_vehicle b = orc_simulate(&ov, rud, thr, t, 0.01 * (i % 9), -0.02 * (i % 5));
+        CHECK(a.state.x() == b.s.x && a.state.y() == b.s.y && a.state.heading() == b.s.heading);
+        CHECK(a.state.speed() == b.s.speed && a.rpm == b.rpm && a.state.time() == b.s.time);
+        CHECK(a.courseMadeGood == b.cmg && a.speedOverGround == b.sog);
+    }
+}
+
+static void estimateTests()
+{
+    VehicleState s1(State(0, 0, 2, 2.3, 7));
+    auto a = s1.simulate(0, 1, 3, std::make_pair(0.0, 0.0)), b = s1.simulate(0, 1, 3, std::make_pair(0.0, 0.0));
+    CHECK(a.state.x() == b.state.x() && a.state.y() == b.state.y() && a.state.time() == b.state.time());      /* estimateTest0 */
+    auto f = s1.simulate(0, 1, 5), s3 = s1.simulate(0, 1, 2).simulate(0, 1, 3);
+    CHECK(ulps(f.state.x(), s3.state.x()) <= 4 && ulps(f.state.y(), s3.state.y()) <= 4);                      /* estimateTest1 */
+    CHECK(ulps(f.state.time(), s3.state.time()) <= 4 && ulps(f.state.heading(), s3.state.heading()) <= 4);
+    VehicleState start(State(0, 0, 0, 0, 4));
+    auto p = start.simulate(0.8, 1, 0.75).simulate(0.8, 1, 0.25), q = start.simulate(0.8, 1, 1);              /* estimateTest2 */
+    CHECK_NEAR(p.state.x(), q.state.x(), 1e-3); CHECK_NEAR(p.state.y(), q.state.y(), 1e-3);
+    CHECK_NEAR(p.state.heading(), q.state.heading(), 1e-3); CHECK_NEAR(p.state.speed(), q.state.speed(), 1e-3);
+}
+
+static void currentEstimatorTests()
+{
+    {   /* currentEstimatorTest1: the reference returns (0, 0) here (20 skips, < 10 samples), SURVEY.md section 4 */
+        CurrentEstimator ce;
+        VehicleState start(State(0, 0, 0, 0, 1));
+        ce.updateEstimate(start.state, -0.8, 1);
+        start = start.simulate(-0.8, 1, 1);
+        start.state.x() -= 0.4;
+        auto c = ce.getCurrent(start.state);
+        CHECK(c.first == 0.0 && c.second == 0.0);
+    }
+    {   /* enough history: equals the oracle's replay, and recovers the current that was applied */
+        CurrentEstimator ce;
+        VehicleState v(State(5, 5, 1.0, 2.0, 100.0));
+        orc_history_entry hist[64]; int n = 0;
+        for (int i = 0; i < 50; i++) {
+            ce.updateEstimate(v.state, 0.25, 0.75);
+            if (i >= 20) { hist[n].s = to_orc(v.state); hist[n].rudder = 0.25; hist[n].throttle = 0.75; n++; }
+            v = v.simulate(0.25, 0.75, 0.1, std::make_pair(0.3, -0.15));
+        }
+        auto c = ce.getCurrent(v.state);
+        double ox, oy;
+        orc_current_estimate(hist, n, 1, to_orc(v.state), &ox, &oy);
+        CHECK(c.first == ox && c.second == oy);
+        /* loose: the replay restarts from rpm(speed) of the oldest sample (VehicleState.h:21), not the true rpm */
+        CHECK_NEAR(c.first, 0.3, 0.1); CHECK_NEAR(c.second, -0.15, 0.1);
+        ce.disable();
+        CHECK(ce.getCurrent(v.state).first == 0.0);
+        ce.enable(); ce.resetEstimate();
+        CHECK(ce.getCurrent(v.state).first == 0.0);
+    }
+}
+
+static DubinsPlan semicircle(double* endTime = nullptr, double truncateSeconds = -1)
+{
+    DubinsPath path;
+    path.qi[0] = 0; path.qi[1] = 0; path.qi[2] = State(0, 0, 0, 2.5, 4).yaw();
+    path.param[0] = 0; path.param[1] = M_PI; path.param[2] = 0;
+    path.type = LRL; path.rho = 8;
+    DubinsWrapper w;
+    w.fill(path, 2.5, 4);
+    if (endTime) *endTime = w.getEndTime();
+    if (truncateSeconds > 0) w.updateEndTime(4 + truncateSeconds);
+    DubinsPlan plan;
+    plan.append(w);
+    return plan;
+}
+
+static void planAndCompareStates()
+{
+    double end;
+    DubinsPlan plan = semicircle(&end);
+    CHECK(end == 8 * M_PI / 2.5 + 4);                                      /* ASSERT_DOUBLE_EQ, test_controller.cpp:467 */
+    CHECK(plan.getEndTime() == end);
+    State s; s.time() = end; plan.sample(s);
+    CHECK_NEAR(s.x(), 16, 1e-12); CHECK_NEAR(s.y(), 0, 1e-12); CHECK_NEAR(s.heading(), M_PI, 1e-12);
+    /* plan sampling equals the oracle's */
+    const double qi[3] = {0, 0, M_PI / 2}, param[3] = {0, M_PI, 0};
+    orc_dubins od; orc_dubins_fill(&od, qi, param, 8, ORC_LRL, 2.5, 4);
+    for (double t = 3.0; t < end + 1; t += 0.37) {
+        State a; a.time() = t; plan.sample(a);
+        orc_state b{0, 0, 0, 0, t}; orc_plan_sample(&od, 1, &b);
+        CHECK(a.x() == b.x && a.y() == b.y && a.heading() == b.heading && a.speed() == b.speed);
+    }
+    /* compareStates == the oracle's, with the weights of the reference's test (updateConfig(..., 1, 1, 0, ...)) and defaults */
+    NodeStub stub(true, 0.0);
+    Controller c(&stub);
+    for (int k = 0; k < 2; k++) {
+        if (k == 0) c.updateConfig(0.0625, 0.125, 1, 1, 0, 0, true, 0); else c.updateConfig(0.0625, 0.125, 1, 20, 5, 20, true, 5);
+        VehicleState v = VehicleState(State(1, 2, 0.3, 2.0, 10)).simulate(0.3, 0.8, 1.0, std::make_pair(0.2, -0.1));
+        State ref(2.5, 3.5, 0.9, 2.5, 11);
+        orc_vehicle ov{to_orc(v.state), v.rpm, v.courseMadeGood, v.speedOverGround};
+        orc_state oref = to_orc(ref);
+        const double want = k == 0 ? orc_compare_states(&oref, &ov, 1, 1, 0) : orc_compare_states(&oref, &ov, 1, 20, 5);
+        CHECK(c.compareStates(ref, v) == want);
+    }
+}
+
+/* ---- GPU ----------------------------------------------------------------------------------------------------- */
+static void mpcMatchesOracle(double planSeconds, double cx, double cy)
+{
+    NodeStub stub(true, 1000.0);                               /* frozen clock: depth is set by the plan length */
+    Controller c(&stub);
+    c.updateConfig(0.0625, 0.125, 1, 20, 5, 20, true, 5);
+    c.updateDisturbanceEstimate(cx, cy);
+    c.setTrajectoryNumber(7);
+    DubinsPlan plan = semicircle(nullptr, planSeconds);
+    State start(0, 0, 0, 2.5, 4);
+    Controller::MpcState got = c.mpc(start, plan, 1e18, 7);
+
+    orc_config cfg; orc_default_config(&cfg); cfg.current_x = cx; cfg.current_y = cy;
+    const double qi[3] = {0, 0, M_PI / 2}, param[3] = {0, M_PI, 0};
+    orc_dubins od; orc_dubins_fill(&od, qi, param, 8, ORC_LRL, 2.5, 4); od.end_time = 4 + planSeconds;
+    const int mi = orc_max_iterations(&od, 1, 4.0);
+    orc_state cps[16];
+    for (int i = 0; i < mi; i++) { cps[i].time = 4.0 + (i + 1); orc_plan_sample(&od, 1, &cps[i]); }
+    orc_mpc_state traj[17]; orc_level_result lv[16]; uint64_t nodes;
+    const int it = orc_mpc_tree(&cfg, to_orc(start), cps, mi, -1, traj, lv, &nodes);
+    CHECK(it == mi);
+    CHECK(got.LastRudder == traj[1].last_rudder && got.LastThrottle == traj[1].last_throttle);
+    CHECK(std::fabs(got.Score - traj[1].score) <= 1e-12 * traj[1].score);
+    CHECK(std::fabs(got.state.state.x() - traj[1].v.s.x) <= 1e-12 && std::fabs(got.state.state.y() - traj[1].v.s.y) <= 1e-12);
+    CHECK(got.state.state.time() == traj[1].v.s.time);
+    CHECK(std::fabs(got.state.courseMadeGood - traj[1].v.cmg) <= 1e-12 && std::fabs(got.state.speedOverGround - traj[1].v.sog) <= 1e-12);
+    CHECK(stub.displayed == 1 && (int)stub.lastTrajectory.size() == it + 1);
+    for (int l = 0; l <= it; l++) {
+        CHECK(std::fabs(stub.lastTrajectory[l].x() - traj[l].v.s.x) <= 1e-11 && std::fabs(stub.lastTrajectory[l].y() - traj[l].v.s.y) <= 1e-11);
+        CHECK(stub.lastTrajectory[l].time() == traj[l].v.s.time);
+    }
+}
+
+static void mpcErrorBehaviour()
+{
+    NodeStub stub(true, 1000.0);
+    Controller c(&stub);
+    c.updateConfig(0.0625, 0.125, 1, 20, 5, 20, true, 5);
+    c.setTrajectoryNumber(3);
+    DubinsPlan plan = semicircle(nullptr, 4.5);
+    State start(0, 0, 0, 2.5, 4);
+    CHECK(c.mpc(start, plan, 1e18, 99).state.state.time() == -1);            /* stale number -> default MpcState (:30-32) */
+    bool threw = false;
+    try { c.mpc(start, DubinsPlan(), 1e18, 3); } catch (const std::runtime_error& e) { threw = std::string(e.what()) == "Cannot run MPC on an empty plan"; }
+    CHECK(threw);
+    threw = false;                                                            /* deadline already passed (:101 -> :196) */
+    try { c.mpc(start, plan, 999.0, 3); } catch (const std::runtime_error& e) { threw = std::string(e.what()) == "MPC failed to complete a single iteration"; }
+    CHECK(threw);
+    threw = false;                                                            /* plan too short for one iteration (:61, :80, :196) */
+    try { c.mpc(start, semicircle(nullptr, 1.5), 1e18, 3); } catch (const std::runtime_error& e) { threw = std::string(e.what()) == "MPC failed to complete a single iteration"; }
+    CHECK(threw);
+}
+
+/* ControllerTests.updateReferenceTrajectoryTest (test_controller.cpp:449-479), shortened: real clock, the MPC thread
+ * issues controls at its own pace while positions are fed along the plan; no numeric assertion in the reference. */
+static void updateReferenceTrajectoryTest()
+{
+    VehicleState start(State(0, 0, 0, 2.5, 4));
+    NodeStub stub(false);
+    Controller controller(&stub);
+    controller.updateConfig(0.0625, 0.125, 1, 1, 0, 0, true, 2);
+    controller.updatePosition(start.state);
+    double end;
+    DubinsPlan plan = semicircle(&end);
+    CHECK(plan.getEndTime() == 8 * M_PI / 2.5 + 4);
+    State result = controller.updateReferenceTrajectory(plan, 0, true);
+    CHECK(std::isfinite(result.x()) && std::isfinite(result.y()) && result.time() > 4.9 && result.time() < 5.1);
+    CHECK(stub.controls.size() >= 1);
+    for (int i = 0; i < 12; i++) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        start.state.time() += 0.05;
+        plan.sample(start.state);
+        controller.updatePosition(start.state);
+    }
+    controller.terminate();
+    std::this_thread::sleep_for(std::chrono::milliseconds(300));
+    CHECK(stub.controls.size() >= 3);                                         /* the MPC thread kept issuing controls */
+    for (auto& rt : stub.controls) CHECK(rt.first >= -1 && rt.first <= 1 && rt.second >= 0 && rt.second <= 1);
+    std::fprintf(stderr, "updateReferenceTrajectoryTest: %zu controls issued, %d trajectories displayed\n", stub.controls.size(), stub.displayed);
+}
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    if (!gpu) {
+        headingTowardsTest();
+        vehicleStateMatchesOracleBitForBit();
+        estimateTests();
+        currentEstimatorTests();
+        planAndCompareStates();
+    } else {
+        mpcMatchesOracle(3.5, 0.2, -0.1);
+        mpcMatchesOracle(4.5, 0.2, -0.1);
+        mpcMatchesOracle(5.5, 0.2, -0.1);
+        mpcMatchesOracle(6.5, 0.0, 0.0);
+        mpcErrorBehaviour();
+        updateReferenceTrajectoryTest();
+    }
+    std::printf("%s: %d checks, %d failed\n", gpu ? "gpu" : "cpu", g_checks, g_failed);
+    return g_failed ? 1 : 0;
+}
