@@ -242,7 +242,12 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
                 }
     /* one wave per workgroup while the set is small (spreads the waves over all SIMDs), 256 lanes otherwise */
     uint32_t block = (count * h->n_probs >= (1u << 20)) ? 256u : 64u;
-    if (const char *e = getenv("MPC_K1_BLOCK")) block = (uint32_t)atoi(e);   /* experiments only */
+    /* Wave-pair form (rollout_pair_kernel): measured SLOWER than the plain kernel on config 2 in round 1 (85 us vs
+     * 71 us: the speed half alone is a long dependent chain and the pose wave waits for it at every barrier), so
+     * it is off unless MPC_PAIR=1 asks for it; kept because it is bit-identical and the idea needs a better split. */
+    bool pair = false;
+    if (const char *e = getenv("MPC_PAIR")) pair = precision == MPC_PREC_FAST && atoi(e) != 0;
+    if (pair) block = 64;                        /* candidates per workgroup (its two waves share them) */
     const uint64_t nblk64 = (count + block - 1) / block;
     if (nblk64 > 0x7FFFFFFFull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
     const uint32_t nblk = (uint32_t)nblk64;
@@ -275,9 +280,15 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     hipLaunchKernelGGL((rollout_kernel<PREC, SEEDED>), grid, blk, lds, h->stream, h->d_probs, d_rud, d_thr,   \
                        first, count, selection, rel, d_cost_last, d_cost_cum, h->d_keys, d_snap, snap_depth,  \
                        h->d_pkey, h->d_pord, h->d_pcnt)
-    if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
+#define LAUNCH_K1P(SEEDED)                                                                                    \
+    hipLaunchKernelGGL((rollout_pair_kernel<SEEDED>), grid, dim3(128), lds + sizeof(double) * 2 * PAIR_CHUNK * 128, \
+                       h->stream, h->d_probs, d_rud, d_thr, first, count, selection, rel, d_cost_last, d_cost_cum, \
+                       h->d_keys, d_snap, snap_depth, h->d_pkey, h->d_pord, h->d_pcnt)
+    if (pair) { if (seeded) LAUNCH_K1P(true); else LAUNCH_K1P(false); }
+    else if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
     else { if (seeded) LAUNCH_K1(MPC_PREC_FAST, true); else LAUNCH_K1(MPC_PREC_FAST, false); }
 #undef LAUNCH_K1
+#undef LAUNCH_K1P
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[2], h->stream));
 #define LAUNCH_K2(SEEDED)                                                                                     \

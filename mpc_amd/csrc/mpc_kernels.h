@@ -173,6 +173,125 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* K1, wave-pair form (fast model): the same arithmetic split over TWO waves per 64 candidates.            */
+/*                                                                                                          */
+/* A 65,536-candidate set is only 1024 wavefronts -- one per SIMD on 256 CUs x 4 SIMDs -- and one wave      */
+/* alone keeps its SIMD's FP64 pipe ~55 % busy (dependent-issue latency; rocprof SQ_ACTIVE_INST_VALU).      */
+/* The model splits cleanly: the speed half (rpm, v) never reads the pose, the pose half (sin h, cos h, x,  */
+/* y, cost) needs only a = yaw*dt and delta = v*dt per substep.  Wave 0 of a 128-lane workgroup runs the    */
+/* speed half one chunk of PAIR_CHUNK substeps AHEAD and hands (a, delta) to wave 1 through a two-slot LDS   */
+/* ring; one workgroup barrier per chunk.  2048 waves -> two per SIMD -> the pipe stays fed.                */
+/* Bit-identical to rollout_kernel<MPC_PREC_FAST>: same device functions, same order.                       */
+/* ------------------------------------------------------------------------------------------------------ */
+#define PAIR_CHUNK 10
+
+template <bool SEEDED>
+__global__ __launch_bounds__(128) void rollout_pair_kernel(const DevProblem *__restrict__ probs,
+                                                           const float *__restrict__ rud, const float *__restrict__ thr,
+                                                           uint64_t first, uint64_t count, int selection, double refine_rel,
+                                                           double *__restrict__ cost_last, double *__restrict__ cost_cum,
+                                                           double *__restrict__ keys, double *__restrict__ snap_base,
+                                                           int snap_depth, uint64_t *__restrict__ pkey,
+                                                           uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt)
+{
+    extern __shared__ double lds[];
+    const DevProblem &P = probs[blockIdx.y];
+    double *cpL = lds;
+    double *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    double *ring = subL + MPC_MAX_SUBSTEPS * SUB_STRIDE;          /* [2][PAIR_CHUNK][2][64] */
+    stage_problem(P, cpL, subL);
+
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;   /* 0: speed half, 1: pose half */
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    const bool live = i < count;
+    const uint64_t ic = live ? i : count - 1;                      /* idle lanes shadow the last candidate */
+    const int nsub = P.nsub, depth = P.depth;
+    const int cpl = (nsub + PAIR_CHUNK - 1) / PAIR_CHUNK;          /* chunks per level */
+    const int total = depth * cpl;
+    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t};
+    const Snap snap{snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count, count, ic};
+    const bool do_snap = snap_base && live;
+    const Weights w{P.wd, P.wh, P.ws};
+    const double *q_last = subL + (nsub - 1) * SUB_STRIDE;
+
+    /* speed half state */
+    double rpm = P.srpm, v = P.sv;
+    FastLevelCoef coef{0, 0, 0};
+    /* pose half state */
+    FastVeh s;
+    s.x = P.sx; s.y = P.sy; s.v = 0; s.rpm = 0; s.delta = 0; s.sh = 0; s.ch = 1;
+    if (role == 1) sincos(P.sh, &s.sh, &s.ch);
+    double last = 0.0, cum = 0.0;
+
+    for (int t = 0; t <= total; t++) {
+        if (role == 0) {
+            if (t < total) {
+                const int l = t / cpl, ck = t - l * cpl;
+                const int k0 = ck * PAIR_CHUNK, k1 = min(k0 + PAIR_CHUNK, nsub);
+                if (ck == 0) {
+                    double r, th;
+                    fetch_control<SEEDED>(c, first + ic, ic, l, r, th);
+                    coef = fast_level_coef(r, th);
+                }
+                double *slot = ring + (size_t)(t & 1) * PAIR_CHUNK * 128 + lane;
+#pragma unroll 5
+                for (int k = k0; k < k1; k++) {
+                    double a, delta;
+                    fast_speed_substep(rpm, v, coef, subL + k * SUB_STRIDE, a, delta);
+                    slot[(k - k0) * 128] = a;
+                    slot[(k - k0) * 128 + 64] = delta;
+                }
+                if (ck == cpl - 1 && do_snap) { snap.put(l, 4, v); snap.put(l, 5, rpm); }
+            }
+        } else {
+            if (t >= 1) {
+                const int tt = t - 1;
+                const int l = tt / cpl, ck = tt - l * cpl;
+                const int k0 = ck * PAIR_CHUNK, k1 = min(k0 + PAIR_CHUNK, nsub);
+                const double *slot = ring + (size_t)(tt & 1) * PAIR_CHUNK * 128 + lane;
+#pragma unroll 5
+                for (int k = k0; k < k1; k++) {
+                    const double a = slot[(k - k0) * 128];
+                    s.delta = slot[(k - k0) * 128 + 64];
+                    fast_pose_substep(s.x, s.y, s.sh, s.ch, a, s.delta);
+                }
+                if (ck == cpl - 1) {
+                    last = fast_score(cpL + l * CP_STRIDE, s, w, q_last);
+                    cum += last;
+                    if (do_snap) {
+                        snap.put(l, 0, s.x); snap.put(l, 1, s.y); snap.put(l, 2, s.sh); snap.put(l, 3, s.ch);
+                        snap.put(l, 6, s.delta); snap.put(l, 7, cum); snap.put(l, 8, last);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    /* the pose wave owns the result: costs, key, argmin and near-tie count of the workgroup's 64 candidates */
+    if (role == 1) {
+        uint64_t k = ~0ull, o = ~0ull;
+        double mykey = __longlong_as_double((long long)KEY_INF);
+        if (live) {
+            const uint64_t at = (uint64_t)blockIdx.y * count + i;
+            if (cost_last) cost_last[at] = last;
+            if (cost_cum) cost_cum[at] = cum;
+            k = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
+            o = first + i;
+            mykey = __longlong_as_double((long long)k);
+            keys[at] = mykey;
+        }
+        wave_argmin(k, o);
+        const double m = __longlong_as_double((long long)k);
+        const uint32_t n_near = (uint32_t)__popcll(__ballot(live && (mykey <= m + m * refine_rel)));
+        if (lane == 0) {
+            const uint64_t b = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
+            pkey[b] = k; pord[b] = o; pcnt[b] = n_near;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* K2: per problem -- reduce, refine list, strict decision among near-ties, the winner's trajectory        */
 /* ------------------------------------------------------------------------------------------------------ */
 template <bool SEEDED>

@@ -159,42 +159,62 @@ __device__ inline double fast_sqrt(double a)
     return fma(e, hh, g);
 }
 
-__device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
+/* The fast model in two halves, so that a candidate can also be split over a pair of waves (rollout_pair_kernel):
+ *   speed half  (rpm, v)        needs throttle and cos/sin of the rudder angle; emits a = yaw_rate*dt and delta = v*dt
+ *   pose half   (sh, ch, x, y)  needs only a and delta */
+struct FastLevelCoef { double target_rpm, kpc, kyaw; };
+
+__device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle)
 {
     rudder = fmin(fmax(rudder, -1.0), 1.0);
     throttle = fmin(fmax(throttle, 0.0), 1.0);
-    const double target_rpm = throttle * MAX_RPM;
     double sin_ra, cos_ra;
     sincos(rudder * MAX_RUDDER_ANGLE, &sin_ra, &cos_ra);
-    const double kpc = PROP_COEFFICIENT * cos_ra;              /* thrust_fwd = kpc * (ps^2 - v^2)        */
-    const double kyaw = (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra;   /* yaw_rate = kyaw * rudder_speed */
+    /* thrust_fwd = kpc * (ps^2 - v^2);  yaw_rate = kyaw * rudder_speed */
+    return FastLevelCoef{throttle * MAX_RPM, PROP_COEFFICIENT * cos_ra, (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra};
+}
+
+__device__ inline void fast_speed_substep(double &rpm, double &v, const FastLevelCoef &c, const double *q,
+                                          double &a, double &delta)
+{
     constexpr double C_PROP = PROP_RATIO / PROP_PITCH;
+    const double dt = q[0], max_step = q[1], dt_over_mass = q[2];
+    /* rpm slew: rpm += clamp((target - rpm)/dt, +-1000) * dt  ==  clamp(target, rpm - 1000 dt, rpm + 1000 dt) */
+    rpm = fmin(fmax(c.target_rpm, rpm - max_step), rpm + max_step);
+    const double ps = C_PROP * rpm;
+    const double rudder_speed = fmax(fast_sqrt1(ps), v);
+    const double v2 = v * v;
+    const double thrust_fwd = c.kpc * fma(ps, ps, -v2);
+    const double force = fma(-DRAG_COEFFICIENT, v2 * v, thrust_fwd);
+    a = (c.kyaw * dt) * rudder_speed;
+    v = fma(force, dt_over_mass, v);
+    delta = v * dt;
+}
+
+/* heading += a as a rotation of (sin h, cos h); |a| <= 0.05 rad for dt <= 0.1 s, where the degree-5/6 Taylor
+ * polynomials are good to 1.5e-13 absolute (2e-15 at dt = 0.05); then the Euler position update */
+__device__ inline void fast_pose_substep(double &x, double &y, double &sh, double &ch, double a, double delta)
+{
+    const double a2 = a * a;
+    const double sa = a * fma(a2, fma(a2, 1.0 / 120, -1.0 / 6), 1.0);
+    const double ca = fma(a2, fma(a2, fma(a2, -1.0 / 720, 1.0 / 24), -0.5), 1.0);
+    const double nsh = fma(sh, ca, ch * sa);
+    const double nch = fma(ch, ca, -(sh * sa));
+    sh = nsh; ch = nch;
+    x = fma(delta, nsh, x);
+    y = fma(delta, nch, y);
+}
+
+__device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
+{
+    const FastLevelCoef c = fast_level_coef(rudder, throttle);
 #ifdef MPC_SUBSTEP_UNROLL
 #pragma unroll MPC_SUBSTEP_UNROLL
 #endif
     for (int k = 0; k < n_sub; k++) {
-        const double *q = sub + k * SUB_STRIDE;
-        const double dt = q[0], max_step = q[1], dt_over_mass = q[2];
-        /* rpm slew: rpm += clamp((target - rpm)/dt, +-1000) * dt  ==  clamp(target, rpm - 1000 dt, rpm + 1000 dt) */
-        s.rpm = fmin(fmax(target_rpm, s.rpm - max_step), s.rpm + max_step);
-        const double ps = C_PROP * s.rpm;
-        const double rudder_speed = fmax(fast_sqrt1(ps), s.v);
-        const double v2 = s.v * s.v;
-        const double thrust_fwd = kpc * fma(ps, ps, -v2);
-        const double force = fma(-DRAG_COEFFICIENT, v2 * s.v, thrust_fwd);
-        /* heading += yaw_rate*dt as a rotation of (sin h, cos h); |a| <= 0.05 rad for dt <= 0.1 s, where the
-         * degree-5/6 Taylor polynomials are good to 1.5e-13 absolute (2e-15 at dt = 0.05) */
-        const double a = (kyaw * dt) * rudder_speed;
-        const double a2 = a * a;
-        const double sa = a * fma(a2, fma(a2, 1.0 / 120, -1.0 / 6), 1.0);
-        const double ca = fma(a2, fma(a2, fma(a2, -1.0 / 720, 1.0 / 24), -0.5), 1.0);
-        const double sh = fma(s.sh, ca, s.ch * sa);
-        const double ch = fma(s.ch, ca, -(s.sh * sa));
-        s.sh = sh; s.ch = ch;
-        s.v = fma(force, dt_over_mass, s.v);
-        s.delta = s.v * dt;
-        s.x = fma(s.delta, sh, s.x);
-        s.y = fma(s.delta, ch, s.y);
+        double a;
+        fast_speed_substep(s.rpm, s.v, c, sub + k * SUB_STRIDE, a, s.delta);
+        fast_pose_substep(s.x, s.y, s.sh, s.ch, a, s.delta);
     }
 }
 
