@@ -9,6 +9,10 @@ A "step" is one MPC solve over one batch of candidates with everything resident 
 near-ties and the winner's trajectory.  With N > 1 every rank evaluates its own 65,536-candidate shard of one
 N x 65,536 set (weak scaling) and the shards are combined by an RCCL min-allreduce of the
 packed (score bits, ordinal) winner.  Rank 0 prints ONE JSON line.
+
+--workload config4 / config5 time the other single-GPU-sized pieces of BASELINE.json (one GPU's 2^21-candidate
+shard of the 16 M x 30 s set; 4096/N vessels x 8192 candidates) with the same contract; the default is config 2,
+the configuration the metric is quoted on.
 """
 import argparse
 import json
@@ -22,7 +26,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_CAND = 65536
-DEPTH = 20
 FLOP_PER_STEP = 54           # VehicleState::estimate as written
 FLOP_PER_SCORE = 21          # Controller::compareStates
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak = half the 157.3 TFLOP/s FP32 vector peak (MI355X_MICROARCH.md)
@@ -51,12 +54,23 @@ def cpu_baseline(problem, seed, want_ordinal):
     }
 
 
+def measured_traffic():
+    """HBM bytes per rollout-kernel launch from the committed PMC profile of this same command (rocprofv3 --pmc
+    cannot run inside the timed process); None if no profile has been committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        return json.load(open(path))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", choices=["fast", "f64"], default="fast")
+    ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,7 +80,7 @@ def main():
     from mpc_amd import workloads as W
     from mpc_amd.distributed import combine_winners
 
-    rank =int(os.environ.get("RANK", "0"))
+    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -82,23 +96,51 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         solver = M.Solver(local, stream=stream.cuda_stream)
-        problem = W.config2_problem(DEPTH)
-        # this rank's shard of the seeded set, as explicit FP32 SoA controls [depth][n] resident in HBM
-        first = rank * N_CAND
-        rud, thr = W.seeded_controls(W.SEED, first, N_CAND, DEPTH, problem.last_rudder, problem.last_throttle)
-        d_rud = torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous()
-        d_thr = torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous()
-        d_last = torch.empty(N_CAND, dtype=torch.float64, device="cuda")
-        d_cum = torch.empty(N_CAND, dtype=torch.float64, device="cuda")
-        win = torch.zeros(2, dtype=torch.int64, device="cuda")
-        solver.upload([problem], [W.SEED])
+        combine = world > 1
+        if args.workload == "config2":
+            depth, count, n_problems = 20, N_CAND, 1
+            problem = W.config2_problem(depth)
+            first = rank * count
+            # this rank's shard of the seeded set, as explicit FP32 SoA controls [depth][n] resident in HBM
+            rud, thr = W.seeded_controls(W.SEED, first, count, depth, problem.last_rudder, problem.last_throttle)
+            d_rud = torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous()
+            d_thr = torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous()
+            d_last = torch.empty(count, dtype=torch.float64, device="cuda")
+            d_cum = torch.empty(count, dtype=torch.float64, device="cuda")
+            solver.upload([problem], [W.SEED])
+            launch = lambda: solver.run_candidates(d_rud, d_thr, count, prec, M.SELECT_LAST_STEP, d_last, d_cum)
+            offset = first
+            what = ("BASELINE config 2: 65,536 seeded candidates per GPU x 20 s horizon (20 levels x 20 Euler substeps "
+                    "of 0.05 s), curved Dubins reference (LSR+RSL+LRL, rho 8 m, 2.5 m/s), explicit FP32 SoA controls "
+                    "resident in HBM")
+        elif args.workload == "config4":
+            depth, count, n_problems = 30, 1 << 21, 1
+            problem = W.config2_problem(depth)
+            first = rank * count
+            solver.upload([problem], [W.SEED])
+            launch = lambda: solver.run_seeded(first, count, prec)
+            offset = 0                                     # the library already reports global ordinals
+            what = ("BASELINE config 4: 2^21 device-generated candidates per GPU (one shard of the 16 M set at 8 GPUs) x "
+                    "30 s horizon (30 x 20 substeps)")
+        else:
+            depth, count = 20, 8192
+            n_problems = 4096 // world
+            probs, seeds = W.fleet_problems(4096, depth)
+            probs, seeds = probs[rank * n_problems:(rank + 1) * n_problems], seeds[rank * n_problems:(rank + 1) * n_problems]
+            problem = probs[0]
+            first = 0
+            solver.upload(probs, seeds)
+            launch = lambda: solver.run_seeded(0, count, prec)
+            offset, combine = 0, False                     # problems are sharded: no collective on the data path
+            what = "BASELINE config 5: 4096 vessels (sharded over the GPUs) x 8,192 candidates x 20 s horizon"
+        win = torch.zeros(2 * n_problems, dtype=torch.int64, device="cuda")
 
         def step():
-            solver.run_candidates(d_rud, d_thr, N_CAND, prec, M.SELECT_LAST_STEP, d_last, d_cum)
-            if world > 1:
+            launch()
+            if combine:
                 # non-negative doubles order like their bit patterns: min score, then min ordinal among the holders
                 solver.copy_winners(win)
-                return combine_winners(win, ordinal_offset=first)
+                return combine_winners(win, ordinal_offset=offset)
             return None
 
         for _ in range(args.warmup):
@@ -109,7 +151,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step()
+            step()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -123,49 +165,53 @@ def main():
         elapsed = float(t.item())
 
         # p50 solve latency: host call -> result struct filled, including the problem upload and the result copy
-        lat = []
-        for _ in range(min(max(args.steps, 20), 200)):
-            torch.cuda.synchronize()
-            a = time.perf_counter()
-            r1 = solver.eval_candidates(problem, d_rud, d_thr, N_CAND, prec, M.SELECT_LAST_STEP, d_last, d_cum)
-            lat.append((time.perf_counter() - a) * 1e3)
-        p50 = float(np.median(lat))
+        p50 = None
+        if args.workload == "config2":
+            lat = []
+            for _ in range(min(max(args.steps, 20), 200)):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                solver.eval_candidates(problem, d_rud, d_thr, count, prec, M.SELECT_LAST_STEP, d_last, d_cum)
+                lat.append((time.perf_counter() - a) * 1e3)
+            p50 = float(np.median(lat))
 
-    steps_per_solve = N_CAND * DEPTH * problem.n_substeps
+    nsub = problem.n_substeps
+    steps_per_solve = n_problems * count * depth * nsub
     value = world * steps_per_solve * args.steps / elapsed
     k1_ms = k1_ms_sum / max(runs, 1)
-    flop = N_CAND * DEPTH * (FLOP_PER_STEP * problem.n_substeps + FLOP_PER_SCORE)
-    hbm_bytes = N_CAND * (2 * 4 * DEPTH + 3 * 8)        # FP32 rudder+throttle per level in; last, cum, key out
+    flop = n_problems * count * depth * (FLOP_PER_STEP * nsub + FLOP_PER_SCORE)
+    hbm_bytes = n_problems * count * ((2 * 4 * depth if args.workload == "config2" else 0) + 3 * 8)
     if rank == 0:
         line = {
             "metric": "candidate_rollout_steps_per_sec",
             "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if prec == M.PREC_F64 else "f64 (fast kernel: FP64 state, FP32 atan2)",
+            "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 65,536 seeded candidates per GPU x 20 s horizon (20 levels x 20 "
-                                   "Euler substeps of 0.05 s), curved Dubins reference (LSR+RSL+LRL, rho 8 m, 2.5 m/s), "
-                                   "explicit FP32 SoA controls resident in HBM",
-                       "candidates_per_gpu": N_CAND, "depth": DEPTH, "substeps_per_level": problem.n_substeps,
-                       "precision": args.precision, "selection": "last_step",
-                       "parallelism": "candidate shards, RCCL min-allreduce" if world > 1 else "single GPU"},
+            "config": {"workload": what, "candidates_per_gpu": n_problems * count, "problems_per_gpu": n_problems,
+                       "depth": depth, "substeps_per_level": nsub,
+                       "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
+                       "selection": "last_step",
+                       "parallelism": ("candidate shards, RCCL min-allreduce" if combine else
+                                       ("problem shards, no collective" if world > 1 else "single GPU"))},
             "p50_solve_latency_ms": p50,
             "rollout_kernel_ms": k1_ms,
             "solve_gpu_ms": total_ms_sum / max(runs, 1),
-            "chosen": {"ordinal": int(res.best_ordinal) + first, "rudder": res.first_rudder,
+            "chosen": {"ordinal": int(res.best_ordinal) + offset, "rudder": res.first_rudder,
                        "throttle": res.first_throttle, "last_score": res.best_last},
             "roofline": {
                 "bound": "valu (FP64 vector; not mfma, not hbm -- sequential per-candidate ODE integration)",
                 "kernel": "rollout_kernel", "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flop / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": measured_traffic() if args.workload == "config2" and prec == M.PREC_FAST else None,
+                "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                 "algorithmic_flop_per_launch": flop, "kernel_steps_per_sec": steps_per_solve / (k1_ms * 1e-3),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,
                         "achieved_GBps": hbm_bytes / (k1_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config2":
             line["cpu_baseline"] = cpu_baseline(problem, W.SEED, int(res.best_ordinal))
         print(json.dumps(line), flush=True)
     solver.close()
