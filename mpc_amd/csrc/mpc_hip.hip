@@ -248,7 +248,8 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     bool pair = false;
     if (const char *e = getenv("MPC_PAIR")) pair = precision == MPC_PREC_FAST && atoi(e) != 0;
     if (pair) block = 64;                        /* candidates per workgroup (its two waves share them) */
-    const uint64_t nblk64 = (count + block - 1) / block;
+    const uint32_t cpb = block;                   /* candidates per workgroup */
+    const uint64_t nblk64 = (count + cpb - 1) / cpb;
     if (nblk64 > 0x7FFFFFFFull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
     const uint32_t nblk = (uint32_t)nblk64;
     if (int s = ensure_keys(h, (size_t)h->n_probs * count)) return s;
@@ -293,7 +294,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     HIP_TRY(hipEventRecord(ev[2], h->stream));
 #define LAUNCH_K2(SEEDED)                                                                                     \
     hipLaunchKernelGGL((finish_kernel<SEEDED>), dim3(h->n_probs), dim3(256), 0, h->stream, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, fast, rel, nblk, block, h->d_pkey, h->d_pord, h->d_pcnt, h->d_keys, \
+                       first, count, selection, fast, rel, nblk, cpb, h->d_pkey, h->d_pord, h->d_pcnt, h->d_keys, \
                        d_snap, snap_depth, h->d_winners, h->d_results)
     if (seeded) LAUNCH_K2(true); else LAUNCH_K2(false);
 #undef LAUNCH_K2
