@@ -81,13 +81,17 @@ extern "C" int mpc_hip_create(int device, void *stream, mpc_hip_handle **out)
     if (device < 0 || device >= n) { mpc_set_err("device index out of range"); return MPC_ERR_NO_DEVICE; }
     mpc_hip_handle *h = new mpc_hip_handle();
     h->device = device;
-    HIP_TRY(hipSetDevice(device));
-    if (stream) h->stream = (hipStream_t)stream;
-    else { HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
-    h->ev.resize(4 * TIMING_RING);
-    for (auto &e : h->ev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipMalloc(&h->d_controls, sizeof(double) * 2 * MPC_MAX_DEPTH));
-    HIP_TRY(hipHostMalloc(&h->h_pair, sizeof(uint64_t) * 8));
+    h->ev.assign(4 * TIMING_RING, nullptr);
+    const int s = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        if (stream) h->stream = (hipStream_t)stream;
+        else { HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+        for (auto &e : h->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipMalloc(&h->d_controls, sizeof(double) * 2 * MPC_MAX_DEPTH));
+        HIP_TRY(hipHostMalloc(&h->h_pair, sizeof(uint64_t) * 8));
+        return MPC_OK;
+    }();
+    if (s != MPC_OK) { mpc_hip_destroy(h); return s; }       /* nothing of a half-built handle leaks */
     *out = h;
     return MPC_OK;
 }
@@ -272,15 +276,26 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     }
     const int fast = precision == MPC_PREC_FAST;
     const double rel = fast ? MPC_REFINE_REL : 0.0;
+    /* all substeps of a level equally long (configs 2-5): the kernels keep the schedule row in registers */
+    bool uniform = true;
+    for (uint32_t p = 0; p < h->n_probs && uniform; p++)
+        for (int s = 1; s < h->nsub[p]; s++)
+            if (h->h_probs[p].sub[s * SUB_STRIDE] != h->h_probs[p].sub[0]) { uniform = false; break; }
     hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
     const dim3 grid(nblk, h->n_probs), blk(block);
-    const size_t lds = sizeof(double) * (MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + sizeof(uint64_t) * 12;
+    /* explicit sets: all levels' controls of a workgroup staged in LDS (FP32) while that stays <= 64 KiB */
+    const size_t ctl_bytes = seeded ? 0 : sizeof(float) * 2 * (size_t)snap_depth * block;
+    const int stage_ctl = !seeded && ctl_bytes <= (64u << 10);
+    const size_t lds = sizeof(double) * (MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + sizeof(uint64_t) * 12 +
+                       (stage_ctl ? ctl_bytes : 0);
     HIP_TRY(hipEventRecord(ev[0], h->stream));
     HIP_TRY(hipEventRecord(ev[1], h->stream));
 #define LAUNCH_K1(PREC, SEEDED)                                                                               \
-    hipLaunchKernelGGL((rollout_kernel<PREC, SEEDED>), grid, blk, lds, h->stream, h->d_probs, d_rud, d_thr,   \
+    if (uniform) LAUNCH_K1U(PREC, SEEDED, true); else LAUNCH_K1U(PREC, SEEDED, false)
+#define LAUNCH_K1U(PREC, SEEDED, UNI)                                                                         \
+    hipLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI>), grid, blk, lds, h->stream, h->d_probs, d_rud, d_thr, \
                        first, count, selection, rel, d_cost_last, d_cost_cum, h->d_keys, d_snap, snap_depth,  \
-                       h->d_pkey, h->d_pord, h->d_pcnt)
+                       stage_ctl, h->d_pkey, h->d_pord, h->d_pcnt)
 #define LAUNCH_K1P(SEEDED)                                                                                    \
     hipLaunchKernelGGL((rollout_pair_kernel<SEEDED>), grid, dim3(128), lds + sizeof(double) * 2 * PAIR_CHUNK * 128, \
                        h->stream, h->d_probs, d_rud, d_thr, first, count, selection, rel, d_cost_last, d_cost_cum, \
@@ -289,6 +304,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     else if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
     else { if (seeded) LAUNCH_K1(MPC_PREC_FAST, true); else LAUNCH_K1(MPC_PREC_FAST, false); }
 #undef LAUNCH_K1
+#undef LAUNCH_K1U
 #undef LAUNCH_K1P
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[2], h->stream));

@@ -24,7 +24,25 @@ struct ControlSource {
     uint64_t n;                  /* stride of the explicit arrays */
     uint64_t seed;               /* seeded */
     double last_r, last_t;
+    const float *staged;         /* explicit controls of THIS lane staged in LDS by stage_controls(), or nullptr */
+    uint32_t staged_stride;      /* = blockDim.x */
 };
+
+/* K1 reads every level's controls of its candidates ONCE, all loads in flight together, into LDS
+ * ([level][rudder|throttle][lane], FP32): one memory latency per kernel instead of one per level (a lone wave per
+ * SIMD has nothing to hide those behind; rocprof showed a third of its life in s_waitcnt). */
+__device__ inline void stage_controls(const float *__restrict__ rud, const float *__restrict__ thr, uint64_t n,
+                                      uint64_t index, bool live, int depth, float *ctl)
+{
+    if (live) {
+#pragma unroll 8
+        for (int l = 0; l < depth; l++) {
+            ctl[(2 * l) * blockDim.x + threadIdx.x] = rud[(uint64_t)l * n + index];
+            ctl[(2 * l + 1) * blockDim.x + threadIdx.x] = thr[(uint64_t)l * n + index];
+        }
+    }
+    /* each lane reads back only what it wrote: no barrier needed */
+}
 
 template <bool SEEDED>
 __device__ inline void fetch_control(const ControlSource &c, uint64_t ordinal, uint64_t index, int level,
@@ -32,6 +50,9 @@ __device__ inline void fetch_control(const ControlSource &c, uint64_t ordinal, u
 {
     if (SEEDED) {
         mpc_candidate_control(c.seed, ordinal, (uint32_t)level, c.last_r, c.last_t, &r, &t);
+    } else if (c.staged) {
+        r = (double)c.staged[(2 * level) * c.staged_stride];
+        t = (double)c.staged[(2 * level + 1) * c.staged_stride];
     } else {
         r = (double)c.rud[(uint64_t)level * c.n + index];
         t = (double)c.thr[(uint64_t)level * c.n + index];
@@ -40,7 +61,8 @@ __device__ inline void fetch_control(const ControlSource &c, uint64_t ordinal, u
 
 __device__ inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-/* Per-level state snapshots, SoA: field f of level l of candidate i at base[(l*SNAP_FIELDS + f)*stride + i].
+/* Per-level state snapshots, SoA (passed BY VALUE: a pointer to it would put the record in scratch memory and turn
+ * every store into a flat_ store that the LDS waits then have to drain; base == nullptr = no snapshots): field f of level l of candidate i at base[(l*SNAP_FIELDS + f)*stride + i].
  * strict: x y h v rpm cmg sog cum last      fast: x y sh ch v rpm delta cum last  (x, y through the water) */
 #define SNAP_FIELDS 9
 struct Snap {
@@ -49,29 +71,34 @@ struct Snap {
     __device__ inline double get(int l, int f) const { return base[((uint64_t)l * SNAP_FIELDS + f) * stride + i]; }
 };
 
+/* Both evaluators: UNIFORM = every substep of a level has the same length (BASELINE configs 2-5: 20 x 0.05 s), so
+ * the schedule row lives in registers instead of being re-read from LDS 400 times per candidate. */
+
 /* strict evaluation of one candidate; traj (optional) receives depth+1 level states */
-template <bool SEEDED>
+template <bool SEEDED, bool UNIFORM = false>
 __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const double *subL,
                                    const ControlSource &c, uint64_t ordinal, uint64_t index,
-                                   double &last, double &cum, mpc_level_state *traj, const Snap *snap)
+                                   double &last, double &cum, mpc_level_state *traj, const Snap snap)
 {
     Veh s{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
     const Weights w{P.wd, P.wh, P.ws};
+    const double row0[1] = {subL[0]};
     last = 0.0; cum = 0.0;
     if (traj) traj[0] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l < P.depth; l++) {
         double r, t;
         fetch_control<SEEDED>(c, ordinal, index, l, r, t);
-        strict_level(s, r, t, subL, P.nsub, P.cx, P.cy);
+        if (UNIFORM) strict_level<0>(s, r, t, row0, P.nsub, P.cx, P.cy);
+        else strict_level<SUB_STRIDE>(s, r, t, subL, P.nsub, P.cx, P.cy);
         last = strict_score(cpL + l * CP_STRIDE, s, w);
         cum += last;
         if (traj)
             traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog,
                                           clampd(r, -1, 1), clampd(t, 0, 1), cum};
-        if (snap) {
-            snap->put(l, 0, s.x); snap->put(l, 1, s.y); snap->put(l, 2, s.h); snap->put(l, 3, s.v);
-            snap->put(l, 4, s.rpm); snap->put(l, 5, s.cmg); snap->put(l, 6, s.sog); snap->put(l, 7, cum);
-            snap->put(l, 8, last);
+        if (snap.base) {
+            snap.put(l, 0, s.x); snap.put(l, 1, s.y); snap.put(l, 2, s.h); snap.put(l, 3, s.v);
+            snap.put(l, 4, s.rpm); snap.put(l, 5, s.cmg); snap.put(l, 6, s.sog); snap.put(l, 7, cum);
+            snap.put(l, 8, last);
         }
     }
 }
@@ -90,31 +117,33 @@ __device__ inline mpc_level_state fast_to_level_state(const double *cp, const do
                            clampd(r, -1, 1), clampd(t, 0, 1), cum};
 }
 
-template <bool SEEDED>
+template <bool SEEDED, bool UNIFORM = false>
 __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const double *subL,
                                  const ControlSource &c, uint64_t ordinal, uint64_t index,
-                                 double &last, double &cum, mpc_level_state *traj, const Snap *snap)
+                                 double &last, double &cum, mpc_level_state *traj, const Snap snap)
 {
     FastVeh s;
     s.x = P.sx; s.y = P.sy; s.v = P.sv; s.rpm = P.srpm; s.delta = 0;
     sincos(P.sh, &s.sh, &s.ch);
     const Weights w{P.wd, P.wh, P.ws};
     const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
+    const double row0[3] = {subL[0], subL[1], subL[2]};
     last = 0.0; cum = 0.0;
     if (traj) traj[0] = mpc_level_state{s.x, s.y, P.sh, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l < P.depth; l++) {
         double r, t;
         fetch_control<SEEDED>(c, ordinal, index, l, r, t);
-        fast_level(s, r, t, subL, P.nsub);
+        if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub);
+        else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub);
         last = fast_score(cpL + l * CP_STRIDE, s, w, q_last);
         cum += last;
         if (traj)
             traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta,
                                               r, t, cum);
-        if (snap) {
-            snap->put(l, 0, s.x); snap->put(l, 1, s.y); snap->put(l, 2, s.sh); snap->put(l, 3, s.ch);
-            snap->put(l, 4, s.v); snap->put(l, 5, s.rpm); snap->put(l, 6, s.delta); snap->put(l, 7, cum);
-            snap->put(l, 8, last);
+        if (snap.base) {
+            snap.put(l, 0, s.x); snap.put(l, 1, s.y); snap.put(l, 2, s.sh); snap.put(l, 3, s.ch);
+            snap.put(l, 4, s.v); snap.put(l, 5, s.rpm); snap.put(l, 6, s.delta); snap.put(l, 7, cum);
+            snap.put(l, 8, last);
         }
     }
 }
@@ -122,31 +151,34 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
 /* ------------------------------------------------------------------------------------------------------ */
 /* K1: rollout + cost + block argmin                                                                       */
 /* ------------------------------------------------------------------------------------------------------ */
-template <int PREC, bool SEEDED>
+template <int PREC, bool SEEDED, bool UNIFORM>
 __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restrict__ probs,
                                                       const float *__restrict__ rud, const float *__restrict__ thr,
                                                       uint64_t first, uint64_t count, int selection, double refine_rel,
                                                       double *__restrict__ cost_last, double *__restrict__ cost_cum,
                                                       double *__restrict__ keys, double *__restrict__ snap_base,
-                                                      int snap_depth, uint64_t *__restrict__ pkey,
+                                                      int snap_depth, int stage_ctl, uint64_t *__restrict__ pkey,
                                                       uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt)
 {
     extern __shared__ double lds[];
     const DevProblem &P = probs[blockIdx.y];
     double *cpL = lds;
     double *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
-    uint64_t *red = (uint64_t *)(subL + MPC_MAX_SUBSTEPS * SUB_STRIDE);       /* 8 words argmin + 2 words */
+    uint64_t *red = (uint64_t *)(subL + MPC_MAX_SUBSTEPS * SUB_STRIDE);       /* 8 words argmin + 2 words (+ 2 pad) */
+    float *ctlL = (float *)(red + 12);                                         /* [depth][2][blockDim] (explicit sets) */
     stage_problem(P, cpL, subL);
 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!SEEDED && stage_ctl) stage_controls(rud, thr, count, i, i < count, P.depth, ctlL);
     uint64_t k = ~0ull, o = ~0ull;
     double mykey = __longlong_as_double((long long)KEY_INF);
     if (i < count) {
-        const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t};
-        const Snap snap{snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count, count, i};
+        const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
+                              (!SEEDED && stage_ctl) ? ctlL + threadIdx.x : nullptr, blockDim.x};
+        const Snap snap{snap_base ? snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count : nullptr, count, i};
         double last, cum;
-        if (PREC == MPC_PREC_F64) eval_strict<SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap_base ? &snap : nullptr);
-        else eval_fast<SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap_base ? &snap : nullptr);
+        if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
+        else eval_fast<SEEDED, UNIFORM>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
         const uint64_t at = (uint64_t)blockIdx.y * count + i;
         if (cost_last) cost_last[at] = last;
         if (cost_cum) cost_cum[at] = cum;
@@ -208,7 +240,7 @@ __global__ __launch_bounds__(128) void rollout_pair_kernel(const DevProblem *__r
     const int nsub = P.nsub, depth = P.depth;
     const int cpl = (nsub + PAIR_CHUNK - 1) / PAIR_CHUNK;          /* chunks per level */
     const int total = depth * cpl;
-    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t};
+    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
     const Snap snap{snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count, count, ic};
     const bool do_snap = snap_base && live;
     const Weights w{P.wd, P.wh, P.ws};
@@ -314,7 +346,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (threadIdx.x == 0) s_n = 0;
     stage_problem(P, cpL, subL);
-    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t};
+    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
     DevResult &R = results[p];
 
     /* 1. the workgroup triples' minimum (lowest ordinal among equal keys) */
@@ -357,7 +389,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
             for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
                 const uint64_t ord = s_list[e];
                 double last, cum;
-                eval_strict<SEEDED>(P, cpL, subL, c, ord, ord - first, last, cum, nullptr, nullptr);
+                eval_strict<SEEDED>(P, cpL, subL, c, ord, ord - first, last, cum, nullptr, Snap{nullptr, 0, 0});
                 lex_min(k2, o2, key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last), ord);
             }
             block_argmin(k2, o2, red);
@@ -405,8 +437,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
         }
     } else if (threadIdx.x == 0) {
         double last = 0, cum = 0;
-        if (keep_fast) eval_fast<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, nullptr);
-        else eval_strict<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, nullptr);
+        if (keep_fast) eval_fast<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
+        else eval_strict<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
         const uint64_t kb = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
         R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
         R.refined = n > 1 ? n : 0; R.overflow = overflow;

@@ -63,6 +63,8 @@ MPC_MODEL_FN inline double rpm_from_speed(double speed)
 /* One level: simulate()'s clamps (VehicleState.h:44-47) and n_sub estimate() calls (:111-148).
  * sin/cos of the rudder angle are loop invariant and cmg/sog are overwritten by every substep, so they are
  * evaluated once / for the last substep only: the values are the ones the reference ends the level with. */
+/* STRIDE: distance between schedule rows; 0 = every substep uses row 0 (a uniform schedule held in registers). */
+template <int STRIDE = SUB_STRIDE>
 MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, const double *sub, int n_sub,
                                     double cx, double cy)
 {
@@ -73,7 +75,7 @@ MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, co
     const double cos_ra = cos(rudder_angle), sin_ra = sin(rudder_angle);
     double dx = 0, dy = 0, d_time = 1;
     for (int k = 0; k < n_sub; k++) {
-        d_time = sub[k * SUB_STRIDE];
+        d_time = sub[k * STRIDE];
         double rcr = (target_rpm - s.rpm) / d_time;
         if (rcr > MAX_RPM_CHANGE_RATE) rcr = MAX_RPM_CHANGE_RATE;
         else if (rcr < -MAX_RPM_CHANGE_RATE) rcr = -MAX_RPM_CHANGE_RATE;
@@ -205,6 +207,7 @@ __device__ inline void fast_pose_substep(double &x, double &y, double &sh, doubl
     y = fma(delta, nch, y);
 }
 
+template <int STRIDE = SUB_STRIDE>
 __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
 {
     const FastLevelCoef c = fast_level_coef(rudder, throttle);
@@ -213,7 +216,7 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
 #endif
     for (int k = 0; k < n_sub; k++) {
         double a;
-        fast_speed_substep(s.rpm, s.v, c, sub + k * SUB_STRIDE, a, s.delta);
+        fast_speed_substep(s.rpm, s.v, c, sub + k * STRIDE, a, s.delta);
         fast_pose_substep(s.x, s.y, s.sh, s.ch, a, s.delta);
     }
 }
