@@ -246,6 +246,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
                 }
     /* one wave per workgroup while the set is small (spreads the waves over all SIMDs), 256 lanes otherwise */
     uint32_t block = (count * h->n_probs >= (1u << 20)) ? 256u : 64u;
+    if (!seeded && h->depth[0] > 32) block = 64;    /* keeps the staged controls (2 * depth * block floats) <= 32 KiB */
     /* Wave-pair form (rollout_pair_kernel): measured SLOWER than the plain kernel on config 2 in round 1 (85 us vs
      * 71 us: the speed half alone is a long dependent chain and the pose wave waits for it at every barrier), so
      * it is off unless MPC_PAIR=1 asks for it; kept because it is bit-identical and the idea needs a better split. */
@@ -283,11 +284,9 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
             if (h->h_probs[p].sub[s * SUB_STRIDE] != h->h_probs[p].sub[0]) { uniform = false; break; }
     hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
     const dim3 grid(nblk, h->n_probs), blk(block);
-    /* explicit sets: all levels' controls of a workgroup staged in LDS (FP32) while that stays <= 64 KiB */
+    /* explicit sets: all levels' controls of a workgroup are staged in LDS as FP32 (<= 64 KiB by the block choice) */
     const size_t ctl_bytes = seeded ? 0 : sizeof(float) * 2 * (size_t)snap_depth * block;
-    const int stage_ctl = !seeded && ctl_bytes <= (64u << 10);
-    const size_t lds = sizeof(double) * (MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + sizeof(uint64_t) * 12 +
-                       (stage_ctl ? ctl_bytes : 0);
+    const size_t lds = sizeof(double) * (MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + sizeof(uint64_t) * 12 + ctl_bytes;
     HIP_TRY(hipEventRecord(ev[0], h->stream));
     HIP_TRY(hipEventRecord(ev[1], h->stream));
 #define LAUNCH_K1(PREC, SEEDED)                                                                               \
@@ -295,7 +294,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
 #define LAUNCH_K1U(PREC, SEEDED, UNI)                                                                         \
     hipLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI>), grid, blk, lds, h->stream, h->d_probs, d_rud, d_thr, \
                        first, count, selection, rel, d_cost_last, d_cost_cum, h->d_keys, d_snap, snap_depth,  \
-                       stage_ctl, h->d_pkey, h->d_pord, h->d_pcnt)
+                       h->d_pkey, h->d_pord, h->d_pcnt)
 #define LAUNCH_K1P(SEEDED)                                                                                    \
     hipLaunchKernelGGL((rollout_pair_kernel<SEEDED>), grid, dim3(128), lds + sizeof(double) * 2 * PAIR_CHUNK * 128, \
                        h->stream, h->d_probs, d_rud, d_thr, first, count, selection, rel, d_cost_last, d_cost_cum, \

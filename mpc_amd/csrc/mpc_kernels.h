@@ -44,13 +44,16 @@ __device__ inline void stage_controls(const float *__restrict__ rud, const float
     /* each lane reads back only what it wrote: no barrier needed */
 }
 
-template <bool SEEDED>
+/* STAGED is a compile-time choice on purpose: a run-time choice between the LDS copy and the global arrays makes
+ * hipcc select between two pointers and emit flat_ loads, whose vmcnt(0)+lgkmcnt(0) wait also drains every
+ * outstanding snapshot store at the top of every level. */
+template <bool SEEDED, bool STAGED = false>
 __device__ inline void fetch_control(const ControlSource &c, uint64_t ordinal, uint64_t index, int level,
                                      double &r, double &t)
 {
     if (SEEDED) {
         mpc_candidate_control(c.seed, ordinal, (uint32_t)level, c.last_r, c.last_t, &r, &t);
-    } else if (c.staged) {
+    } else if (STAGED) {
         r = (double)c.staged[(2 * level) * c.staged_stride];
         t = (double)c.staged[(2 * level + 1) * c.staged_stride];
     } else {
@@ -75,7 +78,7 @@ struct Snap {
  * the schedule row lives in registers instead of being re-read from LDS 400 times per candidate. */
 
 /* strict evaluation of one candidate; traj (optional) receives depth+1 level states */
-template <bool SEEDED, bool UNIFORM = false>
+template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
 __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const double *subL,
                                    const ControlSource &c, uint64_t ordinal, uint64_t index,
                                    double &last, double &cum, mpc_level_state *traj, const Snap snap)
@@ -87,7 +90,7 @@ __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const
     if (traj) traj[0] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l < P.depth; l++) {
         double r, t;
-        fetch_control<SEEDED>(c, ordinal, index, l, r, t);
+        fetch_control<SEEDED, STAGED>(c, ordinal, index, l, r, t);
         if (UNIFORM) strict_level<0>(s, r, t, row0, P.nsub, P.cx, P.cy);
         else strict_level<SUB_STRIDE>(s, r, t, subL, P.nsub, P.cx, P.cy);
         last = strict_score(cpL + l * CP_STRIDE, s, w);
@@ -117,7 +120,7 @@ __device__ inline mpc_level_state fast_to_level_state(const double *cp, const do
                            clampd(r, -1, 1), clampd(t, 0, 1), cum};
 }
 
-template <bool SEEDED, bool UNIFORM = false>
+template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
 __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const double *subL,
                                  const ControlSource &c, uint64_t ordinal, uint64_t index,
                                  double &last, double &cum, mpc_level_state *traj, const Snap snap)
@@ -132,7 +135,7 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
     if (traj) traj[0] = mpc_level_state{s.x, s.y, P.sh, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l < P.depth; l++) {
         double r, t;
-        fetch_control<SEEDED>(c, ordinal, index, l, r, t);
+        fetch_control<SEEDED, STAGED>(c, ordinal, index, l, r, t);
         if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub);
         else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub);
         last = fast_score(cpL + l * CP_STRIDE, s, w, q_last);
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
                                                       uint64_t first, uint64_t count, int selection, double refine_rel,
                                                       double *__restrict__ cost_last, double *__restrict__ cost_cum,
                                                       double *__restrict__ keys, double *__restrict__ snap_base,
-                                                      int snap_depth, int stage_ctl, uint64_t *__restrict__ pkey,
+                                                      int snap_depth, uint64_t *__restrict__ pkey,
                                                       uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt)
 {
     extern __shared__ double lds[];
@@ -169,16 +172,16 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
     stage_problem(P, cpL, subL);
 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (!SEEDED && stage_ctl) stage_controls(rud, thr, count, i, i < count, P.depth, ctlL);
+    if (!SEEDED) stage_controls(rud, thr, count, i, i < count, P.depth, ctlL);
     uint64_t k = ~0ull, o = ~0ull;
     double mykey = __longlong_as_double((long long)KEY_INF);
     if (i < count) {
         const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
-                              (!SEEDED && stage_ctl) ? ctlL + threadIdx.x : nullptr, blockDim.x};
+                              SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x};
         const Snap snap{snap_base ? snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count : nullptr, count, i};
         double last, cum;
-        if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
-        else eval_fast<SEEDED, UNIFORM>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
+        if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
+        else eval_fast<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
         const uint64_t at = (uint64_t)blockIdx.y * count + i;
         if (cost_last) cost_last[at] = last;
         if (cost_cum) cost_cum[at] = cum;
