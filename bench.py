@@ -72,13 +72,15 @@ def main():
     ap.add_argument("--precision", choices=["fast", "f64"], default="fast")
     ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import mpc_amd as M
     from mpc_amd import workloads as W
-    from mpc_amd.distributed import combine_winners
+    from mpc_amd.distributed import ShardCombiner
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,14 +91,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the measured path")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_collective:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     prec = M.PREC_FAST if args.precision == "fast" else M.PREC_F64
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         solver = M.Solver(local, stream=stream.cuda_stream)
-        combine = world > 1
+        combine = world > 1 or args.force_collective
         if args.workload == "config2":
             depth, count, n_problems = 20, N_CAND, 1
             problem = W.config2_problem(depth)
@@ -133,15 +138,16 @@ def main():
             launch = lambda: solver.run_seeded(0, count, prec)
             offset, combine = 0, False                     # problems are sharded: no collective on the data path
             what = "BASELINE config 5: 4096 vessels (sharded over the GPUs) x 8,192 candidates x 20 s horizon"
-        win = torch.zeros(2 * n_problems, dtype=torch.int64, device="cuda")
+        # non-negative doubles order like their bit patterns: (score bits, global ordinal) lexicographic minimum over
+        # the shards = the reference's first strict minimum.  One async all-gather per 16 solves (fewer, larger
+        # collectives), reduced one batch later so that its latency hides behind rollouts (mpc_amd/distributed.py).
+        combiner = ShardCombiner(solver, n_problems, ordinal_stride=(count if args.workload == "config2" else 0),
+                                 always=args.force_collective) if combine else None
 
         def step():
             launch()
-            if combine:
-                # non-negative doubles order like their bit patterns: min score, then min ordinal among the holders
-                solver.copy_winners(win)
-                return combine_winners(win, ordinal_offset=offset)
-            return None
+            if combiner:
+                combiner.submit()
 
         for _ in range(args.warmup):
             step()
@@ -152,6 +158,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        combined = combiner.flush() if combiner else None      # every solve of the timed region is combined by here
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -193,13 +200,14 @@ def main():
                        "depth": depth, "substeps_per_level": nsub,
                        "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
                        "selection": "last_step",
-                       "parallelism": ("candidate shards, RCCL min-allreduce" if combine else
+                       "parallelism": ("candidate shards; one async RCCL all-gather of the packed winners per 16 solves, reduced one batch later" if combine else
                                        ("problem shards, no collective" if world > 1 else "single GPU"))},
             "p50_solve_latency_ms": p50,
             "rollout_kernel_ms": k1_ms,
             "solve_gpu_ms": total_ms_sum / max(runs, 1),
             "chosen": {"ordinal": int(res.best_ordinal) + offset, "rudder": res.first_rudder,
-                       "throttle": res.first_throttle, "last_score": res.best_last},
+                       "throttle": res.first_throttle, "last_score": res.best_last,
+                       "global_ordinal_after_combine": (int(combined[1][0].item()) if combined else None)},
             "roofline": {
                 "bound": "valu (FP64 vector; not mfma, not hbm -- sequential per-candidate ODE integration)",
                 "kernel": "rollout_kernel", "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
@@ -215,7 +223,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(problem, W.SEED, int(res.best_ordinal))
         print(json.dumps(line), flush=True)
     solver.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

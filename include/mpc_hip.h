@@ -175,6 +175,13 @@ int         mpc_hip_device_winners(mpc_hip_handle *h, uint64_t **d_winners);
 /* copy the packed winners (2 uint64 per problem) to caller-owned device memory, on the handle's stream: the
  * form a host that owns its communicator buffers (torch.distributed / RCCL) uses for the min-allreduce */
 int         mpc_hip_copy_winners(mpc_hip_handle *h, uint64_t *d_dst);
+/* Combine the winners of `n_shards` shards after ONE all-gather of the copy_winners records:
+ * d_gathered[shard][problem][2] -> d_out[problem][2] = (smallest score bits, lowest GLOBAL ordinal among the shards
+ * that hold it), global ordinal = gathered ordinal + shard * ordinal_stride (0 if the shards were run with their
+ * first_ordinal).  One tiny kernel on the handle's stream; the reference's first-strict-minimum rule
+ * (controller.cpp:158-166) across GPUs.  No counterpart in the reference (it has one device: none). */
+int         mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards,
+                                   uint32_t n_problems, uint64_t ordinal_stride, uint64_t *d_out);
 /* HIP-event times summed over the runs since the last reset (at most the last 1024 runs): kernel_ms_sum covers
  * the rollout kernel K1 alone, total_ms_sum first launch to last kernel end.  Synchronises the stream. */
 int         mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, double *kernel_ms_sum, double *total_ms_sum);

@@ -416,6 +416,17 @@ extern "C" int mpc_hip_copy_winners(mpc_hip_handle *h, uint64_t *d_dst)
     return MPC_OK;
 }
 
+extern "C" int mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards,
+                                      uint32_t n_problems, uint64_t ordinal_stride, uint64_t *d_out)
+{
+    if (!h || !d_gathered || !d_out || n_shards == 0 || n_problems == 0) { mpc_set_err("combine_shards: NULL or empty argument"); return MPC_ERR_INVALID; }
+    if (int s = mpc_use_device(h)) return s;
+    hipLaunchKernelGGL(combine_shards_kernel, dim3((n_problems + 255) / 256), dim3(256), 0, h->stream, d_gathered, n_shards,
+                       n_problems, ordinal_stride, d_out);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
 static int solve_common(mpc_hip_handle *h, const mpc_problem *probs, const uint64_t *seeds, uint32_t n_problems,
                         bool seeded, const float *d_rud, const float *d_thr, uint64_t first, uint64_t count,
                         int precision, int selection, double *d_cost_last, double *d_cost_cum, mpc_result *results)

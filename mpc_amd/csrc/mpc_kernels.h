@@ -449,6 +449,22 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     }
 }
 
+/* multi-GPU: lexicographic (score bits, global ordinal) minimum over the gathered per-shard winners */
+__global__ __launch_bounds__(256) void combine_shards_kernel(const uint64_t *__restrict__ gathered, uint32_t n_shards,
+                                                             uint32_t n_problems, uint64_t ordinal_stride,
+                                                             uint64_t *__restrict__ out)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_problems) return;
+    uint64_t k = ~0ull, o = ~0ull;
+    for (uint32_t s = 0; s < n_shards; s++) {
+        const uint64_t *g = gathered + ((uint64_t)s * n_problems + p) * 2;
+        const uint64_t ord = g[1] == ~0ull ? ~0ull : g[1] + (uint64_t)s * ordinal_stride;
+        lex_min(k, o, g[0], ord);
+    }
+    out[2 * p] = k; out[2 * p + 1] = o;
+}
+
 /* single explicit control sequence (double precision controls), mpc_hip_rollout */
 __global__ __launch_bounds__(64) void rollout_one_kernel(const DevProblem *__restrict__ probs,
                                                          const double *__restrict__ controls, int precision,

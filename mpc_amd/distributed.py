@@ -22,14 +22,15 @@ def shard_range(n_total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
-def combine_winners(winners, ordinal_offset=0, group=None):
+def combine_winners(winners, ordinal_offset=0, group=None, always=False):
     """winners: int64 tensor [P, 2] (or [2]) on this rank = (score bits, local winning ordinal) per problem, as
     mpc_hip_copy_winners leaves it.  ordinal_offset: what to add to the local ordinals to make them global (0 if
     the library was given first_ordinal).  Returns (score_bits [P], global_ordinal [P]), identical on all ranks.
-    Asynchronous with respect to the host on CUDA tensors (ordered on the current stream)."""
+    Asynchronous with respect to the host on CUDA tensors (ordered on the current stream).  always=True runs the
+    collectives even in a one-rank group (rehearsal)."""
     w = winners.view(-1, 2)
     key = w[:, 0].clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1):
         dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
         cand = torch.where(w[:, 0] == key, w[:, 1] + ordinal_offset, torch.full_like(key, I64_MAX))
         dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=group)
@@ -50,3 +51,84 @@ def owner_rank(global_ordinal, n_total, world):
 
 def bits_to_score(bits):
     return np.asarray(bits.cpu().numpy() if hasattr(bits, "cpu") else bits, dtype=np.int64).view(np.float64)
+
+
+def combine_gathered(gathered, n_shards, n_problems, ordinal_stride=0):
+    """torch form of mpc_hip_combine_shards (used on CPU tensors by the gloo tests; on the GPU the library's kernel
+    does this in one launch): gathered int64 [n_shards, n_problems, 2] -> (score_bits [P], global_ordinal [P])."""
+    g = gathered.view(n_shards, n_problems, 2)
+    keys = g[:, :, 0]
+    kmin = keys.min(dim=0).values
+    off = (torch.arange(n_shards, dtype=torch.int64, device=g.device) * ordinal_stride).view(-1, 1)
+    ords = torch.where(g[:, :, 1] == -1, torch.full_like(keys, I64_MAX), g[:, :, 1] + off)
+    cand = torch.where(keys == kmin, ords, torch.full_like(keys, I64_MAX)).min(dim=0).values
+    return kmin, cand
+
+
+class ShardCombiner:
+    """The combine step for throughput runs of independent solves (bench.py --gpus N), batched and pipelined:
+
+        solver.run_*(...) ; combiner.submit()        # per solve
+        key_bits, ordinal = combiner.flush()         # after the last one: every submitted solve is combined
+
+    submit() copies this rank's winners into the next row of a batch buffer; every `batch` solves ONE asynchronous
+    all-gather moves batch x 16 bytes per problem and rank (instead of two dependent 8-byte all-reduces per solve:
+    fewer, larger collectives), and the gathered batch is reduced by mpc_hip_combine_shards (one tiny kernel) only
+    after the NEXT batch's kernels have been enqueued, so the collective's latency hides behind rollouts.
+    ordinal_stride: what separates the shards' local ordinals (0 when the shards were run with their first_ordinal).
+    flush() returns the combined (score bits, global ordinal) of the LAST solve; `results` holds the last batch.
+    """
+
+    def __init__(self, solver, n_problems, ordinal_stride=0, group=None, batch=16, slots=2, always=False):
+        self.solver, self.P, self.stride, self.group = solver, int(n_problems), int(ordinal_stride), group
+        self.B = int(batch)
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.collective = on and (always or self.world > 1)
+        dev = torch.device("cuda", solver.device)
+        row = 2 * self.P
+        self.win = [torch.zeros(self.B * row, dtype=torch.int64, device=dev) for _ in range(slots)]
+        self.gathered = [torch.zeros(self.B * row * self.world, dtype=torch.int64, device=dev) for _ in range(slots)]
+        self.results = torch.zeros(self.B * row, dtype=torch.int64, device=dev)
+        self.work = [None] * slots
+        self.pending = []                    # slots whose batch has been gathered but not reduced, oldest first
+        self.slot, self.fill, self.last = 0, 0, None
+
+    def _reduce(self, r):
+        if self.work[r] is not None:
+            self.work[r].wait()              # the current stream waits for the collective (no host sync)
+            self.work[r] = None
+        src = self.gathered[r] if self.collective else self.win[r]
+        self.solver.combine_shards(src, self.world if self.collective else 1, self.B * self.P, self.stride, self.results)
+
+    def _close_batch(self):
+        r = self.slot
+        if self.collective:
+            self.work[r] = dist.all_gather_into_tensor(self.gathered[r], self.win[r], group=self.group, async_op=True)
+        self.pending.append(r)
+        self.last = (r, self.fill - 1)
+        self.slot, self.fill = (r + 1) % len(self.win), 0
+
+    def submit(self):
+        if self.fill == 0:
+            while self.slot in self.pending:          # about to overwrite a batch that is not reduced yet
+                self._reduce(self.pending.pop(0))
+        row = 2 * self.P
+        self.solver.copy_winners(self.win[self.slot][self.fill * row:(self.fill + 1) * row])
+        self.fill += 1
+        if self.fill == self.B:
+            older = list(self.pending)
+            self._close_batch()
+            for r in older:                           # batches older than the one just closed
+                self._reduce(r)
+                self.pending.remove(r)
+
+    def flush(self):
+        if self.fill:
+            self._close_batch()
+        while self.pending:
+            self._reduce(self.pending.pop(0))
+        if self.last is None:
+            return None
+        o = self.results.view(self.B, self.P, 2)[self.last[1]]
+        return o[:, 0], o[:, 1]

@@ -68,3 +68,32 @@ def test_single_process_combine_is_the_identity():
     w = torch.tensor([[_bits(2.5), 42]], dtype=torch.int64)
     key, cand = combine_winners(w, ordinal_offset=100)
     assert bits_to_score(key)[0] == 2.5 and cand.tolist() == [142]
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpc_amd.distributed import combine_gathered
+    P = 3
+    # per-shard local winners: problem 0 best on rank 1, problem 1 tie (lowest global ordinal wins), problem 2 empty (-1)
+    score = [[5.0, 2.0, float("inf")], [1.5, 2.0, float("inf")]][rank]
+    ordl = [[9, 4, -1], [3, 4, -1]][rank]
+    w = torch.tensor([[_bits(score[p]), ordl[p]] for p in range(P)], dtype=torch.int64).view(-1)
+    g = torch.zeros(world * P * 2, dtype=torch.int64)
+    dist.all_gather_into_tensor(g, w)
+    key, cand = combine_gathered(g, world, P, ordinal_stride=100)
+    out[rank] = (bits_to_score(key).tolist(), cand.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_combine_matches_the_two_allreduce_form():
+    world = 2
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_gather_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert res[0] == res[1]
+    key, cand = res[0]
+    assert key[:2] == [1.5, 2.0] and key[2] == float("inf")
+    assert cand[0] == 100 + 3 and cand[1] == 4 and cand[2] == np.iinfo(np.int64).max

@@ -198,3 +198,41 @@ def test_errors_are_reported_not_swallowed(solver):
     q.depth = 0
     with pytest.raises(M.MpcError):
         solver.eval_seeded(q, 1, 0, 64, M.PREC_F64)
+
+
+def test_combine_shards_kernel(solver):
+    """mpc_hip_combine_shards against the torch form the gloo tests use, on synthetic gathered winners."""
+    torch = _torch()
+    from mpc_amd.distributed import combine_gathered
+    rng = np.random.RandomState(5)
+    shards, P = 8, 777
+    scores = rng.choice([0.5, 1.0, 2.0, 3.5, np.inf], size=(shards, P))
+    ords = rng.randint(0, 65536, size=(shards, P)).astype(np.int64)
+    ords[scores == np.inf] = -1
+    g = np.stack([scores.view(np.int64), ords], axis=-1)
+    d_g = torch.tensor(g, dtype=torch.int64, device="cuda").contiguous()
+    d_out = torch.zeros(2 * P, dtype=torch.int64, device="cuda")
+    solver.combine_shards(d_g, shards, P, 65536, d_out)
+    solver.synchronize()
+    key, cand = combine_gathered(d_g.view(-1), shards, P, 65536)
+    got = d_out.view(-1, 2)
+    assert torch.equal(got[:, 0], key)
+    want = torch.where(cand == np.iinfo(np.int64).max, torch.full_like(cand, -1), cand)
+    assert torch.equal(got[:, 1], want)
+
+
+def test_shard_combiner_single_rank(solver):
+    """ShardCombiner (the batched, pipelined combine bench.py uses) with one rank: the combined winner of every
+    solve is that solve's own winner; partial batches and ring wrap-around included."""
+    from mpc_amd.distributed import ShardCombiner, bits_to_score
+    p = W.config2_problem(depth=5)
+    comb = ShardCombiner(solver, 1, ordinal_stride=0, batch=3, slots=2)
+    want = None
+    for k in range(8):                       # 2 full batches + a partial one
+        solver.upload([p], [100 + k])
+        solver.run_seeded(0, 2048, M.PREC_FAST)
+        comb.submit()
+        want = solver.fetch()[0]
+    key, ordinal = comb.flush()
+    assert int(ordinal[0].item()) == want.best_ordinal
+    assert bits_to_score(key)[0] == want.best_last
