@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--precision", choices=["fast", "f64"], default="fast")
     ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing-period", type=int, default=8,
+                    help="HIP events ride on every n-th solve's dispatches inside the timed region (1 = every solve)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -149,6 +151,7 @@ def main():
             if combiner:
                 combiner.submit()
 
+        solver.set_timing(max(1, min(args.timing_period, args.steps)))
         for _ in range(args.warmup):
             step()
         solver.timing(reset=True)
@@ -165,6 +168,7 @@ def main():
         elapsed = time.perf_counter() - t0
         runs, k1_ms_sum, total_ms_sum = solver.timing(reset=True)
         res = solver.fetch()[0]
+        solver.set_timing(1)
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if world > 1:
@@ -204,6 +208,8 @@ def main():
                                        ("problem shards, no collective" if world > 1 else "single GPU"))},
             "p50_solve_latency_ms": p50,
             "rollout_kernel_ms": k1_ms,
+            "kernel_timing": "HIP events attached to the K1/K2 dispatches of %d of the %d timed solves (every %d-th)" % (
+                runs, args.steps, max(1, min(args.timing_period, args.steps))),
             "solve_gpu_ms": total_ms_sum / max(runs, 1),
             "chosen": {"ordinal": int(res.best_ordinal) + offset, "rudder": res.first_rudder,
                        "throttle": res.first_throttle, "last_score": res.best_last,

@@ -182,8 +182,14 @@ int         mpc_hip_copy_winners(mpc_hip_handle *h, uint64_t *d_dst);
  * (controller.cpp:158-166) across GPUs.  No counterpart in the reference (it has one device: none). */
 int         mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards,
                                    uint32_t n_problems, uint64_t ordinal_stride, uint64_t *d_out);
-/* HIP-event times summed over the runs since the last reset (at most the last 1024 runs): kernel_ms_sum covers
- * the rollout kernel K1 alone, total_ms_sum first launch to last kernel end.  Synchronises the stream. */
+/* Which runs carry HIP events: every `period`-th run of the handle (1 = all, the default; 0 = none).  The events
+ * ride ON the run's two dispatches (the kernels' own begin/end timestamps), but a dispatch with events still
+ * costs ~5 us more than one without, so throughput callers sample (bench.py: every 8th) or switch them off.
+ * A run without events reports kernel_ms = total_ms = 0 in its mpc_result.  No counterpart in the reference. */
+int         mpc_hip_set_timing(mpc_hip_handle *h, uint32_t period);
+/* HIP-event times summed over the TIMED runs since the last reset (at most the last 1024 runs; *runs = how many
+ * were timed): kernel_ms_sum covers the rollout kernel K1 alone (its begin to its end), total_ms_sum K1's begin
+ * to the last kernel's end.  Synchronises the stream. */
 int         mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, double *kernel_ms_sum, double *total_ms_sum);
 
 /* ---- the reference's own candidate set: limited-branching tree (BASELINE config 1) ------------------------

@@ -62,9 +62,13 @@ struct mpc_hip_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    /* ring of event quadruples: 0 first launch, 1 K1 begin, 2 K1 end, 3 last kernel end */
+    /* ring of event quadruples: 0 = K1 begins, 1 = K1 ends, 2 = K2 begins, 3 = last kernel ends.  The candidate-set
+     * runs ATTACH them to the two dispatches (hipExtLaunchKernelGGL: the kernels' own begin/end timestamps, no
+     * extra packets in the queue); only every timing_period-th run carries them (0 = none), timed[] says which. */
     std::vector<hipEvent_t> ev;
+    std::vector<uint8_t> timed;
     uint64_t runs = 0, timing_base = 0;
+    uint32_t timing_period = 1;
 
     DevProblem *d_probs = nullptr, *h_probs = nullptr;          /* h_probs pinned */
     uint32_t cap_probs = 0, n_probs = 0;

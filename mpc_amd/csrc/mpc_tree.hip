@@ -287,8 +287,8 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
     if ((int)h->tree.size() < max_levels + 1) h->tree.resize(max_levels + 1);
 
     hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
+    h->timed[h->runs % TIMING_RING] = 1;
     HIP_TRY(hipEventRecord(ev[0], h->stream));
-    HIP_TRY(hipEventRecord(ev[1], h->stream));
     if (int s = ensure_level(h, h->tree[0], 1)) return s;
     h->tree[0].n = 1;
     hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]));
@@ -346,7 +346,7 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
             memcpy(&h_level_best[it].best_cumulative, &h->h_pair[2], sizeof(double));
         }
     }
-    HIP_TRY(hipEventRecord(ev[2], h->stream));
+    HIP_TRY(hipEventRecord(ev[1], h->stream));
     if (completed == 0) {
         HIP_TRY(hipEventRecord(ev[3], h->stream));
         h->runs++;
@@ -363,7 +363,7 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
     HIP_TRY(hipStreamSynchronize(h->stream));
     const DevResult &R = h->h_results[0];
     float k1 = 0, total = 0;
-    (void)hipEventElapsedTime(&k1, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&k1, ev[0], ev[1]);
     (void)hipEventElapsedTime(&total, ev[0], ev[3]);
     h_result->levels = completed;
     h_result->best_ordinal = R.ordinal;

@@ -236,3 +236,28 @@ def test_shard_combiner_single_rank(solver):
     key, ordinal = comb.flush()
     assert int(ordinal[0].item()) == want.best_ordinal
     assert bits_to_score(key)[0] == want.best_last
+
+
+def test_timing_period_samples_runs_and_changes_no_result(solver):
+    """mpc_hip_set_timing: events ride on every n-th run only; results do not depend on it."""
+    p = W.config2_problem()
+    solver.upload([p], [W.SEED])
+    try:
+        solver.set_timing(1)
+        solver.run_seeded(0, 4096, M.PREC_FAST)
+        ref = solver.fetch()[0]
+        assert ref.kernel_ms > 0 and ref.total_ms >= ref.kernel_ms
+        solver.timing(reset=True)
+        solver.set_timing(3)
+        for _ in range(9):
+            solver.run_seeded(0, 4096, M.PREC_FAST)
+        runs, k_ms, t_ms = solver.timing(reset=True)
+        assert runs == 3 and 0 < k_ms <= t_ms
+        solver.set_timing(0)
+        solver.run_seeded(0, 4096, M.PREC_FAST)
+        res = solver.fetch()[0]
+        assert res.kernel_ms == 0 and res.total_ms == 0
+        assert (res.best_ordinal, res.best_last, res.first_rudder) == (ref.best_ordinal, ref.best_last, ref.first_rudder)
+        assert solver.timing(reset=True)[0] == 0
+    finally:
+        solver.set_timing(1)
