@@ -250,12 +250,6 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     /* one wave per workgroup while the set is small (spreads the waves over all SIMDs), 256 lanes otherwise */
     uint32_t block = (count * h->n_probs >= (1u << 20)) ? 256u : 64u;
     if (!seeded && h->depth[0] > 32) block = 64;    /* keeps the staged controls (2 * depth * block floats) <= 32 KiB */
-    /* Wave-pair form (rollout_pair_kernel): measured SLOWER than the plain kernel on config 2 in round 1 (85 us vs
-     * 71 us: the speed half alone is a long dependent chain and the pose wave waits for it at every barrier), so
-     * it is off unless MPC_PAIR=1 asks for it; kept because it is bit-identical and the idea needs a better split. */
-    bool pair = false;
-    if (const char *e = getenv("MPC_PAIR")) pair = precision == MPC_PREC_FAST && atoi(e) != 0;
-    if (pair) block = 64;                        /* candidates per workgroup (its two waves share them) */
     const uint32_t cpb = block;                   /* candidates per workgroup */
     const uint64_t nblk64 = (count + cpb - 1) / cpb;
     if (nblk64 > 0x7FFFFFFFull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
@@ -302,20 +296,14 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     hipExtLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
                        first, count, selection, rel, d_cost_last, d_cost_cum, h->d_keys, d_snap, snap_depth,  \
                        h->d_pkey, h->d_pord, h->d_pcnt)
-#define LAUNCH_K1P(SEEDED)                                                                                    \
-    hipLaunchKernelGGL((rollout_pair_kernel<SEEDED>), grid, dim3(128), lds + sizeof(double) * 2 * PAIR_CHUNK * 128, \
-                       h->stream, h->d_probs, d_rud, d_thr, first, count, selection, rel, d_cost_last, d_cost_cum, \
-                       h->d_keys, d_snap, snap_depth, h->d_pkey, h->d_pord, h->d_pcnt)
-    if (pair) { if (seeded) LAUNCH_K1P(true); else LAUNCH_K1P(false); }
-    else if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
+    if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
     else { if (seeded) LAUNCH_K1(MPC_PREC_FAST, true); else LAUNCH_K1(MPC_PREC_FAST, false); }
 #undef LAUNCH_K1
 #undef LAUNCH_K1U
-#undef LAUNCH_K1P
     HIP_TRY(hipGetLastError());
 #define LAUNCH_K2(SEEDED)                                                                                     \
     hipExtLaunchKernelGGL((finish_kernel<SEEDED>), dim3(h->n_probs), dim3(256), 0, h->stream, k2a, k2b, 0, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, fast, rel, nblk, cpb, h->d_pkey, h->d_pord, h->d_pcnt, h->d_keys, \
+                       first, count, selection, fast, (int)uniform, rel, nblk, cpb, h->d_pkey, h->d_pord, h->d_pcnt, h->d_keys, \
                        d_snap, snap_depth, h->d_winners, h->d_results)
     if (seeded) LAUNCH_K2(true); else LAUNCH_K2(false);
 #undef LAUNCH_K2

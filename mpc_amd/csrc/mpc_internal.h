@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -141,13 +142,51 @@ __device__ inline void block_argmin(uint64_t &k, uint64_t &o, uint64_t *red)
     }
 }
 
-/* stage checkpoints and substep schedule of one problem into LDS */
+/* Stage checkpoints and substep schedule of one problem into LDS.  DevProblem keeps cp[] and sub[] adjacent and
+ * 16-byte aligned, and the kernels keep cpL / subL adjacent in LDS, so staging is ONE contiguous copy of
+ * STAGE_VEC 16-byte vectors, done in two halves: stage_problem_load() only ISSUES the loads (into registers, all in
+ * flight together and together with whatever the caller loads next), stage_problem_store() writes them to LDS.
+ * The whole arrays are copied whatever the problem's depth: the copy then depends on nothing but the kernel
+ * arguments (no scalar load of P.depth in front of it), and a per-depth loop was one full memory latency per
+ * trip -- the first profile of K1 showed ~11 serialized latencies (~10 us of a 50-us kernel) in its prologue. */
+#define STAGE_VEC ((MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) / 2)
+#define STAGE_TRIPS ((STAGE_VEC + 63) / 64)          /* per-thread vectors at the smallest block (one wave) */
+static_assert(offsetof(DevProblem, cp) % 16 == 0 && sizeof(DevProblem) % 16 == 0, "16-byte staging vectors");
+static_assert(offsetof(DevProblem, sub) == offsetof(DevProblem, cp) + sizeof(double) * MPC_MAX_DEPTH * CP_STRIDE, "cp, sub adjacent");
+
+struct StagedProblem { double2 v[STAGE_TRIPS]; };
+
+__device__ inline void stage_problem_load(const DevProblem &P, StagedProblem &r)
+{
+    const double2 *src = reinterpret_cast<const double2 *>(P.cp);
+#pragma unroll
+    for (int t = 0; t < STAGE_TRIPS; t++) {
+        /* clamped, not predicated: a load under a branch is waited for at the branch's end */
+        const uint32_t idx = min(threadIdx.x + t * blockDim.x, (uint32_t)STAGE_VEC - 1u);
+        r.v[t] = src[idx];
+    }
+}
+
+/* lds = cpL (subL follows it); ends with the workgroup barrier */
+__device__ inline void stage_problem_store(const StagedProblem &r, double *lds)
+{
+    double2 *dst = reinterpret_cast<double2 *>(lds);
+#pragma unroll
+    for (int t = 0; t < STAGE_TRIPS; t++) {
+        /* clamped like the loads (surplus lanes rewrite the last vector with its own value): a predicated store
+         * makes hipcc sink each load into the store's branch, i.e. one exposed latency per trip again */
+        const uint32_t idx = min(threadIdx.x + t * blockDim.x, (uint32_t)STAGE_VEC - 1u);
+        dst[idx] = r.v[t];
+    }
+    __syncthreads();
+}
+
 __device__ inline void stage_problem(const DevProblem &P, double *cpL, double *subL)
 {
-    const int ncp = P.depth * CP_STRIDE, nsb = P.nsub * SUB_STRIDE;
-    for (int i = threadIdx.x; i < ncp; i += blockDim.x) cpL[i] = P.cp[i];
-    for (int i = threadIdx.x; i < nsb; i += blockDim.x) subL[i] = P.sub[i];
-    __syncthreads();
+    StagedProblem r;
+    stage_problem_load(P, r);
+    stage_problem_store(r, cpL);
+    (void)subL;
 }
 
 #endif

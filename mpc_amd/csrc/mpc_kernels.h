@@ -28,17 +28,30 @@ struct ControlSource {
     uint32_t staged_stride;      /* = blockDim.x */
 };
 
-/* K1 reads every level's controls of its candidates ONCE, all loads in flight together, into LDS
- * ([level][rudder|throttle][lane], FP32): one memory latency per kernel instead of one per level (a lone wave per
- * SIMD has nothing to hide those behind; rocprof showed a third of its life in s_waitcnt). */
+/* K1 reads every level's controls of its candidates ONCE into LDS ([level][rudder|throttle][lane], FP32), CTL_CHUNK
+ * levels (2 * CTL_CHUNK loads) in flight together: one memory latency per kernel for depth <= 32 instead of one per
+ * level (a lone wave per SIMD has nothing to hide those behind).  The last chunk repeats the last level rather
+ * than branch (same address, same LDS word).  depth is a KERNEL ARGUMENT here, not P.depth, so the loads do not
+ * wait for a scalar load of the problem record. */
+#define CTL_CHUNK 32
 __device__ inline void stage_controls(const float *__restrict__ rud, const float *__restrict__ thr, uint64_t n,
                                       uint64_t index, bool live, int depth, float *ctl)
 {
     if (live) {
-#pragma unroll 8
-        for (int l = 0; l < depth; l++) {
-            ctl[(2 * l) * blockDim.x + threadIdx.x] = rud[(uint64_t)l * n + index];
-            ctl[(2 * l + 1) * blockDim.x + threadIdx.x] = thr[(uint64_t)l * n + index];
+        for (int base = 0; base < depth; base += CTL_CHUNK) {
+            float a[CTL_CHUNK], b[CTL_CHUNK];
+#pragma unroll
+            for (int j = 0; j < CTL_CHUNK; j++) {
+                const int l = min(base + j, depth - 1);
+                a[j] = rud[(uint64_t)l * n + index];
+                b[j] = thr[(uint64_t)l * n + index];
+            }
+#pragma unroll
+            for (int j = 0; j < CTL_CHUNK; j++) {
+                const int l = min(base + j, depth - 1);
+                ctl[(2 * l) * blockDim.x + threadIdx.x] = a[j];
+                ctl[(2 * l + 1) * blockDim.x + threadIdx.x] = b[j];
+            }
         }
     }
     /* each lane reads back only what it wrote: no barrier needed */
@@ -130,7 +143,7 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
     sincos(P.sh, &s.sh, &s.ch);
     const Weights w{P.wd, P.wh, P.ws};
     const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
-    const double row0[3] = {subL[0], subL[1], subL[2]};
+    const double row0[6] = {subL[0], subL[1], subL[2], subL[3], subL[4], subL[5]};
     last = 0.0; cum = 0.0;
     if (traj) traj[0] = mpc_level_state{s.x, s.y, P.sh, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l < P.depth; l++) {
@@ -163,16 +176,19 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
                                                       int snap_depth, uint64_t *__restrict__ pkey,
                                                       uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const DevProblem &P = probs[blockIdx.y];
     double *cpL = lds;
     double *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     uint64_t *red = (uint64_t *)(subL + MPC_MAX_SUBSTEPS * SUB_STRIDE);       /* 8 words argmin + 2 words (+ 2 pad) */
     float *ctlL = (float *)(red + 12);                                         /* [depth][2][blockDim] (explicit sets) */
-    stage_problem(P, cpL, subL);
-
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (!SEEDED) stage_controls(rud, thr, count, i, i < count, P.depth, ctlL);
+    /* prologue: every global load of the workgroup is issued before the first wait (problem record, then controls;
+     * explicit sets hold one problem, whose depth is snap_depth) */
+    StagedProblem staged;
+    stage_problem_load(P, staged);
+    if (!SEEDED) stage_controls(rud, thr, count, i, i < count, snap_depth, ctlL);
+    stage_problem_store(staged, cpL);
     uint64_t k = ~0ull, o = ~0ull;
     double mykey = __longlong_as_double((long long)KEY_INF);
     if (i < count) {
@@ -208,138 +224,19 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
-/* K1, wave-pair form (fast model): the same arithmetic split over TWO waves per 64 candidates.            */
-/*                                                                                                          */
-/* A 65,536-candidate set is only 1024 wavefronts -- one per SIMD on 256 CUs x 4 SIMDs -- and one wave      */
-/* alone keeps its SIMD's FP64 pipe ~55 % busy (dependent-issue latency; rocprof SQ_ACTIVE_INST_VALU).      */
-/* The model splits cleanly: the speed half (rpm, v) never reads the pose, the pose half (sin h, cos h, x,  */
-/* y, cost) needs only a = yaw*dt and delta = v*dt per substep.  Wave 0 of a 128-lane workgroup runs the    */
-/* speed half one chunk of PAIR_CHUNK substeps AHEAD and hands (a, delta) to wave 1 through a two-slot LDS   */
-/* ring; one workgroup barrier per chunk.  2048 waves -> two per SIMD -> the pipe stays fed.                */
-/* Bit-identical to rollout_kernel<MPC_PREC_FAST>: same device functions, same order.                       */
-/* ------------------------------------------------------------------------------------------------------ */
-#define PAIR_CHUNK 10
-
-template <bool SEEDED>
-__global__ __launch_bounds__(128) void rollout_pair_kernel(const DevProblem *__restrict__ probs,
-                                                           const float *__restrict__ rud, const float *__restrict__ thr,
-                                                           uint64_t first, uint64_t count, int selection, double refine_rel,
-                                                           double *__restrict__ cost_last, double *__restrict__ cost_cum,
-                                                           double *__restrict__ keys, double *__restrict__ snap_base,
-                                                           int snap_depth, uint64_t *__restrict__ pkey,
-                                                           uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt)
-{
-    extern __shared__ double lds[];
-    const DevProblem &P = probs[blockIdx.y];
-    double *cpL = lds;
-    double *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
-    double *ring = subL + MPC_MAX_SUBSTEPS * SUB_STRIDE;          /* [2][PAIR_CHUNK][2][64] */
-    stage_problem(P, cpL, subL);
-
-    const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;   /* 0: speed half, 1: pose half */
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
-    const bool live = i < count;
-    const uint64_t ic = live ? i : count - 1;                      /* idle lanes shadow the last candidate */
-    const int nsub = P.nsub, depth = P.depth;
-    const int cpl = (nsub + PAIR_CHUNK - 1) / PAIR_CHUNK;          /* chunks per level */
-    const int total = depth * cpl;
-    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
-    const Snap snap{snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count, count, ic};
-    const bool do_snap = snap_base && live;
-    const Weights w{P.wd, P.wh, P.ws};
-    const double *q_last = subL + (nsub - 1) * SUB_STRIDE;
-
-    /* speed half state */
-    double rpm = P.srpm, v = P.sv;
-    FastLevelCoef coef{0, 0, 0};
-    /* pose half state */
-    FastVeh s;
-    s.x = P.sx; s.y = P.sy; s.v = 0; s.rpm = 0; s.delta = 0; s.sh = 0; s.ch = 1;
-    if (role == 1) sincos(P.sh, &s.sh, &s.ch);
-    double last = 0.0, cum = 0.0;
-
-    for (int t = 0; t <= total; t++) {
-        if (role == 0) {
-            if (t < total) {
-                const int l = t / cpl, ck = t - l * cpl;
-                const int k0 = ck * PAIR_CHUNK, k1 = min(k0 + PAIR_CHUNK, nsub);
-                if (ck == 0) {
-                    double r, th;
-                    fetch_control<SEEDED>(c, first + ic, ic, l, r, th);
-                    coef = fast_level_coef(r, th);
-                }
-                double *slot = ring + (size_t)(t & 1) * PAIR_CHUNK * 128 + lane;
-#pragma unroll 5
-                for (int k = k0; k < k1; k++) {
-                    double a, delta;
-                    fast_speed_substep(rpm, v, coef, subL + k * SUB_STRIDE, a, delta);
-                    slot[(k - k0) * 128] = a;
-                    slot[(k - k0) * 128 + 64] = delta;
-                }
-                if (ck == cpl - 1 && do_snap) { snap.put(l, 4, v); snap.put(l, 5, rpm); }
-            }
-        } else {
-            if (t >= 1) {
-                const int tt = t - 1;
-                const int l = tt / cpl, ck = tt - l * cpl;
-                const int k0 = ck * PAIR_CHUNK, k1 = min(k0 + PAIR_CHUNK, nsub);
-                const double *slot = ring + (size_t)(tt & 1) * PAIR_CHUNK * 128 + lane;
-#pragma unroll 5
-                for (int k = k0; k < k1; k++) {
-                    const double a = slot[(k - k0) * 128];
-                    s.delta = slot[(k - k0) * 128 + 64];
-                    fast_pose_substep(s.x, s.y, s.sh, s.ch, a, s.delta);
-                }
-                if (ck == cpl - 1) {
-                    last = fast_score(cpL + l * CP_STRIDE, s, w, q_last);
-                    cum += last;
-                    if (do_snap) {
-                        snap.put(l, 0, s.x); snap.put(l, 1, s.y); snap.put(l, 2, s.sh); snap.put(l, 3, s.ch);
-                        snap.put(l, 6, s.delta); snap.put(l, 7, cum); snap.put(l, 8, last);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    /* the pose wave owns the result: costs, key, argmin and near-tie count of the workgroup's 64 candidates */
-    if (role == 1) {
-        uint64_t k = ~0ull, o = ~0ull;
-        double mykey = __longlong_as_double((long long)KEY_INF);
-        if (live) {
-            const uint64_t at = (uint64_t)blockIdx.y * count + i;
-            if (cost_last) cost_last[at] = last;
-            if (cost_cum) cost_cum[at] = cum;
-            k = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
-            o = first + i;
-            mykey = __longlong_as_double((long long)k);
-            keys[at] = mykey;
-        }
-        wave_argmin(k, o);
-        const double m = __longlong_as_double((long long)k);
-        const uint32_t n_near = (uint32_t)__popcll(__ballot(live && (mykey <= m + m * refine_rel)));
-        if (lane == 0) {
-            const uint64_t b = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
-            pkey[b] = k; pord[b] = o; pcnt[b] = n_near;
-        }
-    }
-}
-
-/* ------------------------------------------------------------------------------------------------------ */
 /* K2: per problem -- reduce, refine list, strict decision among near-ties, the winner's trajectory        */
 /* ------------------------------------------------------------------------------------------------------ */
 template <bool SEEDED>
 __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restrict__ probs,
                                                      const float *__restrict__ rud, const float *__restrict__ thr,
                                                      uint64_t first, uint64_t count, int selection, int fast,
-                                                     double refine_rel, uint32_t nblk, uint32_t k1_block,
+                                                     int uniform, double refine_rel, uint32_t nblk, uint32_t k1_block,
                                                      const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
                                                      const uint32_t *__restrict__ pcnt, const double *__restrict__ keys,
                                                      double *__restrict__ snap_base, int snap_depth,
                                                      uint64_t *__restrict__ winners, DevResult *__restrict__ results)
 {
-    __shared__ double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t s_list[LIST_CAP];
     __shared__ uint64_t red[8];
     __shared__ uint64_t s_win[2];
@@ -348,7 +245,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     const DevProblem &P = probs[p];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (threadIdx.x == 0) s_n = 0;
-    stage_problem(P, cpL, subL);
+    /* the problem record's loads are in flight together with the first pass over the triples */
+    StagedProblem staged;
+    stage_problem_load(P, staged);
     const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
     DevResult &R = results[p];
 
@@ -356,6 +255,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     uint64_t k = ~0ull, o = ~0ull;
     for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x)
         lex_min(k, o, pkey[(uint64_t)p * nblk + j], pord[(uint64_t)p * nblk + j]);
+    stage_problem_store(staged, cpL);
     block_argmin(k, o, red);
     if (threadIdx.x == 0) { s_win[0] = k; s_win[1] = o; }
     __syncthreads();
@@ -440,7 +340,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
         }
     } else if (threadIdx.x == 0) {
         double last = 0, cum = 0;
-        if (keep_fast) eval_fast<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
+        /* the same flavour of the fast model as K1 ran (the two differ in rounding), so the result is K1's own */
+        if (keep_fast && uniform) eval_fast<SEEDED, true>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
+        else if (keep_fast) eval_fast<SEEDED, false>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
         else eval_strict<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
         const uint64_t kb = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
         R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;

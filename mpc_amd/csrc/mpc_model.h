@@ -136,19 +136,8 @@ MPC_MODEL_FN inline double strict_score(const double *cp, const Veh &s, const We
  * v*dt, from which the last displacement over ground (for course made good / speed over ground) follows. */
 struct FastVeh { double x, y, sh, ch, v, rpm, delta; };
 
-/* sqrt(a), a >= 0: hardware reciprocal-sqrt estimate + one coupled Newton (Goldschmidt) step, relative error
- * ~1e-13 or better; a == 0 gives ~1e-154 instead of 0 */
-__device__ inline double fast_sqrt1(double a)
-{
-    a = fmax(a, 1.0e-300);
-    const double y = __builtin_amdgcn_rsq(a);
-    const double g = a * y;
-    const double hh = 0.5 * y;
-    const double r = fma(-hh, g, 0.5);
-    return fma(g, r, g);
-}
-
-/* the same with a residual correction (~1 ulp), for the scoring terms */
+/* sqrt(a), a >= 0: hardware reciprocal-sqrt estimate + one coupled Newton (Goldschmidt) step
+ * with a residual correction (~1 ulp), for the scoring terms; a == 0 gives ~1e-154 instead of 0 */
 __device__ inline double fast_sqrt(double a)
 {
     a = fmax(a, 1.0e-300);
@@ -161,63 +150,99 @@ __device__ inline double fast_sqrt(double a)
     return fma(e, hh, g);
 }
 
-/* The fast model in two halves, so that a candidate can also be split over a pair of waves (rollout_pair_kernel):
- *   speed half  (rpm, v)        needs throttle and cos/sin of the rudder angle; emits a = yaw_rate*dt and delta = v*dt
- *   pose half   (sh, ch, x, y)  needs only a and delta */
-struct FastLevelCoef { double target_rpm, kpc, kyaw; };
+/* Per-level constants of the fast model.  The rudder angle lies in [-pi/6, pi/6] (clamped rudder), so sin/cos need
+ * no range reduction: Taylor polynomials to x^13 / x^14 (truncation < 1e-16 relative there) instead of the
+ * library sincos with its reduction paths -- ~18 FMAs instead of ~70 instructions per level. */
+struct FastLevelCoef { double target_rpm, kpc, kyaw; };   /* thrust_fwd = kpc * (ps^2 - v^2);  yaw_rate = kyaw * rudder_speed */
 
 __device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle)
 {
     rudder = fmin(fmax(rudder, -1.0), 1.0);
     throttle = fmin(fmax(throttle, 0.0), 1.0);
-    double sin_ra, cos_ra;
-    sincos(rudder * MAX_RUDDER_ANGLE, &sin_ra, &cos_ra);
-    /* thrust_fwd = kpc * (ps^2 - v^2);  yaw_rate = kyaw * rudder_speed */
+    const double x = rudder * MAX_RUDDER_ANGLE, x2 = x * x;
+    double ps = -1.0 / 6227020800.0;                                   /* -1/13! */
+    ps = fma(ps, x2, 1.0 / 39916800.0);
+    ps = fma(ps, x2, -1.0 / 362880.0);
+    ps = fma(ps, x2, 1.0 / 5040.0);
+    ps = fma(ps, x2, -1.0 / 120.0);
+    ps = fma(ps, x2, 1.0 / 6.0);
+    const double sin_ra = fma(-(x * x2), ps, x);
+    double pc = -1.0 / 87178291200.0;                                  /* -1/14! */
+    pc = fma(pc, x2, 1.0 / 479001600.0);
+    pc = fma(pc, x2, -1.0 / 3628800.0);
+    pc = fma(pc, x2, 1.0 / 40320.0);
+    pc = fma(pc, x2, -1.0 / 720.0);
+    pc = fma(pc, x2, 1.0 / 24.0);
+    pc = fma(pc, x2, -0.5);
+    const double cos_ra = fma(pc, x2, 1.0);
     return FastLevelCoef{throttle * MAX_RPM, PROP_COEFFICIENT * cos_ra, (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra};
 }
 
-__device__ inline void fast_speed_substep(double &rpm, double &v, const FastLevelCoef &c, const double *q,
-                                          double &a, double &delta)
+/* One Euler substep, 28 FP64 instructions (VehicleState.h:111-148 restated for throughput):
+ *   rpm slew   rpm += clamp((target - rpm)/dt, +-1000) * dt  ==  clamp(target, rpm - 1000 dt, rpm + 1000 dt)
+ *   sqrt       rsq estimate + one coupled Newton (Goldschmidt) step; the +1e-300 keeps rsq finite at rpm == 0
+ *   speed      v += dt/m * (kpc (ps^2 - v^2) - D v^3)  as  v - v^2 (kpcm + dm v) + (kpcm ps) ps   (kpcm, dm carry dt/m)
+ *   heading    rotation of (sin h, cos h) by a = yaw_rate*dt, |a| <= 0.05 rad for dt <= 0.1 s: sin to a^5 (2.6e-9 a
+ *              relative), cos - 1 to a^4 (2e-11 absolute), written as corrections to the old vector (no cancellation)
+ *   position   x += step * sin h', y += step * cos h': step = v*dt, or v alone when the caller carries x/dt, y/dt
+ *              through a level of equal substeps (SCALED) */
+template <bool SCALED>
+__device__ inline void fast_substep(double &rpm, double &v, double &sh, double &ch, double &x, double &y,
+                                    double target_rpm, double max_step, double kpcm, double dm, double kyaw_dt,
+                                    double dt)
 {
     constexpr double C_PROP = PROP_RATIO / PROP_PITCH;
-    const double dt = q[0], max_step = q[1], dt_over_mass = q[2];
-    /* rpm slew: rpm += clamp((target - rpm)/dt, +-1000) * dt  ==  clamp(target, rpm - 1000 dt, rpm + 1000 dt) */
-    rpm = fmin(fmax(c.target_rpm, rpm - max_step), rpm + max_step);
-    const double ps = C_PROP * rpm;
-    const double rudder_speed = fmax(fast_sqrt1(ps), v);
+    rpm = fmin(fmax(target_rpm, rpm - max_step), rpm + max_step);
+    const double ps = fma(C_PROP, rpm, 1.0e-300);
+    const double y0 = __builtin_amdgcn_rsq(ps);
+    const double g = ps * y0;
+    const double hh = 0.5 * y0;
+    const double r = fma(-hh, g, 0.5);
+    const double rudder_speed = fmax(fma(g, r, g), v);
+    const double a = kyaw_dt * rudder_speed;
     const double v2 = v * v;
-    const double thrust_fwd = c.kpc * fma(ps, ps, -v2);
-    const double force = fma(-DRAG_COEFFICIENT, v2 * v, thrust_fwd);
-    a = (c.kyaw * dt) * rudder_speed;
-    v = fma(force, dt_over_mass, v);
-    delta = v * dt;
-}
-
-/* heading += a as a rotation of (sin h, cos h); |a| <= 0.05 rad for dt <= 0.1 s, where the degree-5/6 Taylor
- * polynomials are good to 1.5e-13 absolute (2e-15 at dt = 0.05); then the Euler position update */
-__device__ inline void fast_pose_substep(double &x, double &y, double &sh, double &ch, double a, double delta)
-{
+    const double w = fma(dm, v, kpcm);
+    const double kps = kpcm * ps;
+    v = fma(kps, ps, fma(-v2, w, v));
     const double a2 = a * a;
-    const double sa = a * fma(a2, fma(a2, 1.0 / 120, -1.0 / 6), 1.0);
-    const double ca = fma(a2, fma(a2, fma(a2, -1.0 / 720, 1.0 / 24), -0.5), 1.0);
-    const double nsh = fma(sh, ca, ch * sa);
-    const double nch = fma(ch, ca, -(sh * sa));
+    const double sa = fma(a * a2, fma(a2, 1.0 / 120, -1.0 / 6), a);
+    const double cm = a2 * fma(a2, 1.0 / 24, -0.5);                   /* cos a - 1 */
+    const double nsh = fma(sh, cm, fma(ch, sa, sh));
+    const double nch = fma(ch, cm, fma(-sh, sa, ch));
     sh = nsh; ch = nch;
-    x = fma(delta, nsh, x);
-    y = fma(delta, nch, y);
+    const double step = SCALED ? v : v * dt;
+    x = fma(step, nsh, x);
+    y = fma(step, nch, y);
 }
 
+/* STRIDE 0: every substep of the level uses schedule row 0 (held in registers by the caller) */
 template <int STRIDE = SUB_STRIDE>
 __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
 {
     const FastLevelCoef c = fast_level_coef(rudder, throttle);
+    if (STRIDE == 0) {
+        const double dt = sub[0], max_step = sub[1], dtm = sub[2], inv_dt = sub[5];
+        const double kpcm = c.kpc * dtm, dm = DRAG_COEFFICIENT * dtm, kyaw_dt = c.kyaw * dt;
+        double xs = s.x * inv_dt, ys = s.y * inv_dt;
 #ifdef MPC_SUBSTEP_UNROLL
 #pragma unroll MPC_SUBSTEP_UNROLL
 #endif
-    for (int k = 0; k < n_sub; k++) {
-        double a;
-        fast_speed_substep(s.rpm, s.v, c, sub + k * STRIDE, a, s.delta);
-        fast_pose_substep(s.x, s.y, s.sh, s.ch, a, s.delta);
+        for (int k = 0; k < n_sub; k++)
+            fast_substep<true>(s.rpm, s.v, s.sh, s.ch, xs, ys, c.target_rpm, max_step, kpcm, dm, kyaw_dt, dt);
+        s.x = xs * dt; s.y = ys * dt;
+        s.delta = s.v * dt;
+    } else {
+        double dt = 0;
+#ifdef MPC_SUBSTEP_UNROLL
+#pragma unroll MPC_SUBSTEP_UNROLL
+#endif
+        for (int k = 0; k < n_sub; k++) {
+            const double *q = sub + k * STRIDE;
+            dt = q[0];
+            fast_substep<false>(s.rpm, s.v, s.sh, s.ch, s.x, s.y, c.target_rpm, q[1], c.kpc * q[2],
+                                DRAG_COEFFICIENT * q[2], c.kyaw * dt, dt);
+        }
+        if (n_sub > 0) s.delta = s.v * dt;
     }
 }
 

@@ -11,6 +11,8 @@ import mpc_amd as M
 from mpc_amd import workloads as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+if os.environ.get("MPC_LIB"):                      # an experimental build of the library (exp/)
+    M.binding.load_library(os.environ["MPC_LIB"])
 depth, count = 20, 65536
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
@@ -31,5 +33,5 @@ with torch.cuda.stream(stream):
     ms = (time.perf_counter() - t0) * 1e3 / n
     runs, k, tot = solver.timing(reset=True)
     res = solver.fetch()[0]
-print("MPC_EVENTS=%s  wall %.4f ms/solve  k1 %.4f ms  span %.4f ms  ordinal %d score %.12g" % (
-    os.environ.get("MPC_EVENTS", "0"), ms, k / max(runs, 1), tot / max(runs, 1), res.best_ordinal, res.best_last))
+print("lib=%s  wall %.4f ms/solve  k1 %.4f ms  span %.4f ms  ordinal %d score %.12g" % (
+    os.environ.get("MPC_LIB", "default"), ms, k / max(runs, 1), tot / max(runs, 1), res.best_ordinal, res.best_last))
