@@ -77,14 +77,61 @@ __device__ inline void fetch_control(const ControlSource &c, uint64_t ordinal, u
 
 __device__ inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-/* Per-level state snapshots, SoA (passed BY VALUE: a pointer to it would put the record in scratch memory and turn
- * every store into a flat_ store that the LDS waits then have to drain; base == nullptr = no snapshots): field f of level l of candidate i at base[(l*SNAP_FIELDS + f)*stride + i].
- * strict: x y h v rpm cmg sog cum last      fast: x y sh ch v rpm delta cum last  (x, y through the water) */
-#define SNAP_FIELDS 9
+/* Per-level state snapshots, pair-SoA: K1 writes the state after every level as 16-byte pairs (one
+ * global_store_dwordx4 per pair, a wave's 64 lanes = 1 KiB contiguous), pair q of level l of candidate i at
+ * base[((l*SNAP_PAIRS + q)*stride + i)*2 .. +1]; field f lives in pair f/2, slot f%2.
+ *   strict: x y | h v | rpm cmg | sog cum | last -      fast: x y | sh ch | v rpm | cum last   (x, y through the water)
+ * Passed BY VALUE: a pointer to it would put the record in scratch memory and turn every store into a flat_ store
+ * that the LDS waits then have to drain.  base == nullptr = no snapshots. */
+#define SNAP_PAIRS 5
+#define SNAP_FIELDS (2 * SNAP_PAIRS)
+/* K1's side.  The stores are buffer stores with the WRITE-THROUGH cache policy (sc0 sc1): 94 MB of snapshots per
+ * config-2 solve otherwise sit dirty in the XCDs' L2s until the end-of-kernel write-back, which then delays the
+ * next dispatch (measured: plain 42.1 us K1 / 58.7 us per solve, nontemporal 40.0 / 56.3, write-through 39.6 / 55.6;
+ * no snapshots at all 38.5).  The descriptor also moves the level/pair part of the address into a scalar offset:
+ * no 64-bit vector address arithmetic per store. */
+typedef uint32_t mpc_u32x4 __attribute__((ext_vector_type(4)));
+#define MPC_AUX_WRITE_THROUGH 17          /* sc0 (1) | sc1 (16) */
+struct SnapW {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t pair_bytes;         /* 16 * candidates of the problem: distance between consecutive pairs */
+    uint32_t lane_off;           /* 16 * this lane's candidate index */
+    bool on;
+    __device__ inline void put2(int l, int q, double a, double b) const
+    {
+        union { double d[2]; mpc_u32x4 v; } u;
+        u.d[0] = a; u.d[1] = b;
+        __builtin_amdgcn_raw_buffer_store_b128(u.v, rsrc, (int)lane_off, (int)((uint32_t)(l * SNAP_PAIRS + q) * pair_bytes),
+                                               MPC_AUX_WRITE_THROUGH);
+    }
+};
+
+__device__ inline SnapW snap_writer(double *problem_base, uint64_t count, int snap_depth, uint64_t i)
+{
+    SnapW w;
+    const uint64_t bytes = (uint64_t)snap_depth * SNAP_PAIRS * count * 16;      /* <= MPC_SNAPSHOT_BYTES_MAX (host) */
+    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(problem_base, 0, (int)(uint32_t)bytes, 0x00020000);
+    w.pair_bytes = (uint32_t)(count * 16);
+    w.lane_off = (uint32_t)(i * 16);
+    w.on = problem_base != nullptr;
+    return w;
+}
+
+__device__ inline SnapW snap_none()
+{
+    SnapW w;
+    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+    w.pair_bytes = 0; w.lane_off = 0; w.on = false;
+    return w;
+}
+
+/* K2's side: plain loads of the winner's pairs */
 struct Snap {
-    double *base; uint64_t stride, i;
-    __device__ inline void put(int l, int f, double v) const { base[((uint64_t)l * SNAP_FIELDS + f) * stride + i] = v; }
-    __device__ inline double get(int l, int f) const { return base[((uint64_t)l * SNAP_FIELDS + f) * stride + i]; }
+    const double *base; uint64_t stride, i;
+    __device__ inline double get(int l, int f) const
+    {
+        return base[(((uint64_t)l * SNAP_PAIRS + (f >> 1)) * stride + i) * 2 + (f & 1)];
+    }
 };
 
 /* Both evaluators: UNIFORM = every substep of a level has the same length (BASELINE configs 2-5: 20 x 0.05 s), so
@@ -94,7 +141,7 @@ struct Snap {
 template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
 __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const double *subL,
                                    const ControlSource &c, uint64_t ordinal, uint64_t index,
-                                   double &last, double &cum, mpc_level_state *traj, const Snap snap)
+                                   double &last, double &cum, mpc_level_state *traj, const SnapW snap)
 {
     Veh s{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
     const Weights w{P.wd, P.wh, P.ws};
@@ -111,10 +158,9 @@ __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const
         if (traj)
             traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog,
                                           clampd(r, -1, 1), clampd(t, 0, 1), cum};
-        if (snap.base) {
-            snap.put(l, 0, s.x); snap.put(l, 1, s.y); snap.put(l, 2, s.h); snap.put(l, 3, s.v);
-            snap.put(l, 4, s.rpm); snap.put(l, 5, s.cmg); snap.put(l, 6, s.sog); snap.put(l, 7, cum);
-            snap.put(l, 8, last);
+        if (snap.on) {
+            snap.put2(l, 0, s.x, s.y); snap.put2(l, 1, s.h, s.v); snap.put2(l, 2, s.rpm, s.cmg);
+            snap.put2(l, 3, s.sog, cum); snap.put2(l, 4, last, 0.0);
         }
     }
 }
@@ -136,7 +182,7 @@ __device__ inline mpc_level_state fast_to_level_state(const double *cp, const do
 template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
 __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const double *subL,
                                  const ControlSource &c, uint64_t ordinal, uint64_t index,
-                                 double &last, double &cum, mpc_level_state *traj, const Snap snap)
+                                 double &last, double &cum, mpc_level_state *traj, const SnapW snap)
 {
     FastVeh s;
     s.x = P.sx; s.y = P.sy; s.v = P.sv; s.rpm = P.srpm; s.delta = 0;
@@ -156,10 +202,9 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
         if (traj)
             traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta,
                                               r, t, cum);
-        if (snap.base) {
-            snap.put(l, 0, s.x); snap.put(l, 1, s.y); snap.put(l, 2, s.sh); snap.put(l, 3, s.ch);
-            snap.put(l, 4, s.v); snap.put(l, 5, s.rpm); snap.put(l, 6, s.delta); snap.put(l, 7, cum);
-            snap.put(l, 8, last);
+        if (snap.on) {
+            snap.put2(l, 0, s.x, s.y); snap.put2(l, 1, s.sh, s.ch); snap.put2(l, 2, s.v, s.rpm);
+            snap.put2(l, 3, cum, last);
         }
     }
 }
@@ -194,7 +239,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
     if (i < count) {
         const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
                               SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x};
-        const Snap snap{snap_base ? snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count : nullptr, count, i};
+        const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count : nullptr,
+                                       count, snap_depth, i);
         double last, cum;
         if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
         else eval_fast<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
@@ -245,17 +291,38 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     const DevProblem &P = probs[p];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (threadIdx.x == 0) s_n = 0;
-    /* the problem record's loads are in flight together with the first pass over the triples */
-    StagedProblem staged;
-    stage_problem_load(P, staged);
     const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
     DevResult &R = results[p];
+    const uint64_t *pk = pkey + (uint64_t)p * nblk, *po = pord + (uint64_t)p * nblk;
+    const uint32_t *pc = pcnt + (uint64_t)p * nblk;
 
-    /* 1. the workgroup triples' minimum (lowest ordinal among equal keys) */
-    uint64_t k = ~0ull, o = ~0ull;
-    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x)
-        lex_min(k, o, pkey[(uint64_t)p * nblk + j], pord[(uint64_t)p * nblk + j]);
+    /* 1. the workgroup triples' minimum (lowest ordinal among equal keys).  K2 is a chain of memory latencies, so
+     *    every trip keeps FIN_U triples per thread in flight (indices clamped, not predicated: a repeated triple
+     *    does not change a minimum), and the first trip's loads travel together with the problem record's. */
+    constexpr uint32_t FIN_U = 4;
+    uint64_t kk[FIN_U], oo[FIN_U];
+    uint32_t cc[FIN_U];
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_U; u++) {
+        const uint32_t j = min(u * blockDim.x + threadIdx.x, nblk - 1);
+        kk[u] = pk[j]; oo[u] = po[j]; cc[u] = pc[j];
+    }
+    StagedProblem staged;
+    stage_problem_load(P, staged);
     stage_problem_store(staged, cpL);
+    uint64_t k = ~0ull, o = ~0ull;
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_U; u++) lex_min(k, o, kk[u], oo[u]);
+    for (uint32_t base = FIN_U * blockDim.x; base < nblk; base += FIN_U * blockDim.x) {     /* > 1024 workgroups */
+        uint64_t k2[FIN_U], o2[FIN_U];
+#pragma unroll
+        for (uint32_t u = 0; u < FIN_U; u++) {
+            const uint32_t j = min(base + u * blockDim.x + threadIdx.x, nblk - 1);
+            k2[u] = pk[j]; o2[u] = po[j];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < FIN_U; u++) lex_min(k, o, k2[u], o2[u]);
+    }
     block_argmin(k, o, red);
     if (threadIdx.x == 0) { s_win[0] = k; s_win[1] = o; }
     __syncthreads();
@@ -267,22 +334,26 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     if (fast) {
         const double m = __longlong_as_double((long long)k);
         const double limit = m + m * refine_rel;
-        for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) {
-            const uint64_t b = (uint64_t)p * nblk + j;
-            if (__longlong_as_double((long long)pkey[b]) <= limit) {
-                if (pcnt[b] <= 1) {
-                    const uint32_t at = atomicAdd(&s_n, 1u);
-                    if (at < LIST_CAP) s_list[at] = pord[b];
-                } else {                                   /* several near-ties inside one K1 workgroup */
-                    const uint64_t lo = (uint64_t)j * k1_block, hi = min(lo + k1_block, count);
-                    for (uint64_t e = lo; e < hi; e++)
-                        if (keys[(uint64_t)p * count + e] <= limit) {
-                            const uint32_t at = atomicAdd(&s_n, 1u);
-                            if (at < LIST_CAP) s_list[at] = first + e;
-                        }
-                }
+        auto consider = [&](uint32_t j, uint64_t key, uint64_t ord, uint32_t near) {
+            if (__longlong_as_double((long long)key) > limit) return;
+            if (near <= 1) {
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at < LIST_CAP) s_list[at] = ord;
+            } else {                                       /* several near-ties inside one K1 workgroup */
+                const uint64_t lo = (uint64_t)j * k1_block, hi = min(lo + k1_block, count);
+                for (uint64_t e = lo; e < hi; e++)
+                    if (keys[(uint64_t)p * count + e] <= limit) {
+                        const uint32_t at = atomicAdd(&s_n, 1u);
+                        if (at < LIST_CAP) s_list[at] = first + e;
+                    }
             }
+        };
+#pragma unroll
+        for (uint32_t u = 0; u < FIN_U; u++) {               /* the first trip's triples are still in registers */
+            const uint32_t j = u * blockDim.x + threadIdx.x;
+            if (j < nblk) consider(j, kk[u], oo[u], cc[u]);
         }
+        for (uint32_t j = FIN_U * blockDim.x + threadIdx.x; j < nblk; j += blockDim.x) consider(j, pk[j], po[j], pc[j]);
         __syncthreads();
         n = s_n;
         if (n > LIST_CAP) { overflow = 1; n = LIST_CAP; }
@@ -292,7 +363,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
             for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
                 const uint64_t ord = s_list[e];
                 double last, cum;
-                eval_strict<SEEDED>(P, cpL, subL, c, ord, ord - first, last, cum, nullptr, Snap{nullptr, 0, 0});
+                eval_strict<SEEDED>(P, cpL, subL, c, ord, ord - first, last, cum, nullptr, snap_none());
                 lex_min(k2, o2, key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last), ord);
             }
             block_argmin(k2, o2, red);
@@ -321,17 +392,21 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
         if (l < P.depth) {
             double r, t;
             fetch_control<SEEDED>(c, win, win - first, l, r, t);
-            if (fast)
-                R.traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, subL + (P.nsub - 1) * SUB_STRIDE,
+            if (fast) {
+                /* delta = v * (last substep's dt), as fast_level leaves it */
+                const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
+                const double v = snap.get(l, 4);
+                R.traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last,
                                                     snap.get(l, 0), snap.get(l, 1), snap.get(l, 2), snap.get(l, 3),
-                                                    snap.get(l, 4), snap.get(l, 5), snap.get(l, 6), r, t, snap.get(l, 7));
+                                                    v, snap.get(l, 5), v * q_last[0], r, t, snap.get(l, 6));
+            }
             else
                 R.traj[l + 1] = mpc_level_state{snap.get(l, 0), snap.get(l, 1), snap.get(l, 2), snap.get(l, 3),
                                                 snap.get(l, 4), snap.get(l, 5), snap.get(l, 6),
                                                 clampd(r, -1, 1), clampd(t, 0, 1), snap.get(l, 7)};
         }
         if (threadIdx.x == 0) {
-            const double last = snap.get(P.depth - 1, 8), cum = snap.get(P.depth - 1, 7);
+            const double last = snap.get(P.depth - 1, fast ? 7 : 8), cum = snap.get(P.depth - 1, fast ? 6 : 7);
             const uint64_t kb = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
             R.traj[0] = mpc_level_state{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
             R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
@@ -341,9 +416,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     } else if (threadIdx.x == 0) {
         double last = 0, cum = 0;
         /* the same flavour of the fast model as K1 ran (the two differ in rounding), so the result is K1's own */
-        if (keep_fast && uniform) eval_fast<SEEDED, true>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
-        else if (keep_fast) eval_fast<SEEDED, false>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
-        else eval_strict<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, Snap{nullptr, 0, 0});
+        if (keep_fast && uniform) eval_fast<SEEDED, true>(P, cpL, subL, c, win, win - first, last, cum, R.traj, snap_none());
+        else if (keep_fast) eval_fast<SEEDED, false>(P, cpL, subL, c, win, win - first, last, cum, R.traj, snap_none());
+        else eval_strict<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, snap_none());
         const uint64_t kb = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
         R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
         R.refined = n > 1 ? n : 0; R.overflow = overflow;

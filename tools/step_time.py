@@ -12,7 +12,7 @@ from mpc_amd import workloads as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 if os.environ.get("MPC_LIB"):                      # an experimental build of the library (exp/)
-    M.binding.load_library(os.environ["MPC_LIB"])
+    M.binding._lib = M.binding.load_library(os.environ["MPC_LIB"])
 depth, count = 20, 65536
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
