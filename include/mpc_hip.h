@@ -134,7 +134,11 @@ int         mpc_hip_synchronize(mpc_hip_handle *h);
  *   score = compareStates(checkpoint[l], state);  Score += score
  * and the first-strict-minimum selection of controller.cpp:158-166.
  * d_rudders / d_throttles: device, FP32, level-major [depth][n] (SoA: lane i reads element l*n + i).
- * d_cost_last / d_cost_cum: device, FP64 [n], may be NULL.  h_result: host. */
+ * d_cost_last / d_cost_cum: device, FP64 [n], may be NULL.  h_result: host.
+ * A set in which NO candidate has a finite score selects nothing, as nothing is ever below the reference's initial
+ * minScore = DBL_MAX (controller.cpp:81,160): result status MPC_ERR_NO_ITERATION, best_ordinal = UINT64_MAX, packed
+ * winner (+inf bits, UINT64_MAX).  The one-problem calls return that status; the batched call returns MPC_OK and
+ * reports per problem in h_results[p].status. */
 int         mpc_hip_eval_candidates(mpc_hip_handle *h, const mpc_problem *h_problem,
                                     const float *d_rudders, const float *d_throttles, uint64_t n,
                                     int precision, int selection,

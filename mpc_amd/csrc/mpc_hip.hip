@@ -362,6 +362,14 @@ static void fill_result(const mpc_hip_handle *h, uint32_t p, const DevResult &R,
                         mpc_result *out)
 {
     memset(out, 0, sizeof *out);
+    if (R.ordinal == ~0ull) {            /* no candidate with a finite score: nothing selected */
+        out->best_ordinal = R.ordinal;
+        out->best_last = out->best_cumulative = INFINITY;
+        out->evaluated = h->last_count;
+        out->kernel_ms = k1_ms; out->total_ms = total_ms;
+        out->status = MPC_ERR_NO_ITERATION;
+        return;
+    }
     const int D = h->depth[p];
     out->levels = D;
     out->best_ordinal = R.ordinal;
@@ -444,6 +452,12 @@ static int solve_common(mpc_hip_handle *h, const mpc_problem *probs, const uint6
         /* the reported costs stay the fast ones; only the decision is redone (into the library's own buffers) */
         if (int s2 = run_common(h, seeded, d_rud, d_thr, first, count, MPC_PREC_F64, selection, nullptr, nullptr)) return s2;
         s = fetch_internal(h, results, n_problems);
+    }
+    if (s == MPC_OK && n_problems == 1 && results[0].status != MPC_OK) {
+        /* one problem: its status is the call's status (a batch reports per problem in results[p].status) */
+        if (results[0].status == MPC_ERR_NO_ITERATION) mpc_set_err("no candidate has a finite score: nothing is below DBL_MAX (controller.cpp:81,160)");
+        else mpc_set_err("the chosen control is not finite (controller.cpp:201-202)");
+        return results[0].status;
     }
     return s;
 }

@@ -327,11 +327,13 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     if (threadIdx.x == 0) { s_win[0] = k; s_win[1] = o; }
     __syncthreads();
     k = s_win[0]; o = s_win[1];
-    uint64_t win = o;
+    /* no finite score anywhere: nothing is ever below the reference's initial minScore = DBL_MAX
+     * (controller.cpp:81,160), so nothing is selected */
+    uint64_t win = k < KEY_INF ? o : ~0ull;
     uint32_t n = 0, overflow = 0;
 
     /* 2. fast mode: the candidates within refine_rel of the minimum */
-    if (fast) {
+    if (fast && k < KEY_INF) {
         const double m = __longlong_as_double((long long)k);
         const double limit = m + m * refine_rel;
         auto consider = [&](uint32_t j, uint64_t key, uint64_t ord, uint32_t near) {
