@@ -168,6 +168,24 @@ int         mpc_hip_run_seeded(mpc_hip_handle *h, uint64_t first_ordinal, uint64
 int         mpc_hip_run_candidates(mpc_hip_handle *h, const float *d_rudders, const float *d_throttles,
                                    uint64_t n, int precision, int selection,
                                    double *d_cost_last, double *d_cost_cum);
+/* Reference trajectories sampled on the device.  Replaces, for batches, the host loop of
+ * controller.cpp:96-98 -- checkpoint i = referenceTrajectory.sample(start time + (i+1) * 1 s) -- with one kernel
+ * (a lane per problem and level) that writes the checkpoints into the resident problem records; the problems' own
+ * checkpoints[] are ignored, everything else of mpc_upload_problems applies.  mpc_dubins = dubins.h DubinsPath +
+ * DubinsWrapper::fill(path, speed, startTime) (mpc_node.cpp:245-248); DubinsPlan::sample as SURVEY.md 8c defines it
+ * (external to the reference repository: parity unpinned).  Empty plan: MPC_ERR_EMPTY_PLAN (controller.cpp:37). */
+#define MPC_MAX_PLAN_SEGMENTS 8
+typedef struct {
+    double qi[3], param[3], rho;      /* start pose (x, y, yaw), segment lengths in units of rho, turn radius     */
+    int32_t type, reserved;           /* DubinsPathType: LSL, LSR, RSL, RSR, RLR, LRL = 0..5                        */
+    double speed, start_time, end_time;
+} mpc_dubins;
+typedef struct { int32_t n_segments, reserved; mpc_dubins segments[MPC_MAX_PLAN_SEGMENTS]; } mpc_plan;
+int         mpc_hip_upload_problems_from_plans(mpc_hip_handle *h, const mpc_problem *h_problems, const uint64_t *h_seeds,
+                                               const mpc_plan *h_plans, const double *h_start_times,
+                                               uint32_t n_problems);
+/* the checkpoints of one resident problem as the kernels see them (h_out[depth]); for display and tests */
+int         mpc_hip_fetch_checkpoints(mpc_hip_handle *h, uint32_t problem, mpc_checkpoint *h_out);
 /* copy the results of the last run (n_problems of them) to the host; synchronises the stream */
 int         mpc_hip_fetch_results(mpc_hip_handle *h, mpc_result *h_results, uint32_t n_problems);
 /* device address of the per-problem packed winners of the last run: for problem p two uint64,

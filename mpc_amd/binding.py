@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_abi_version", "mpc_hip_status_string", "mpc_hip_last_error", "mpc_hip_default_problem",
     "mpc_hip_substep_schedule", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
-    "mpc_hip_upload_problems", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
+    "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
     "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_combine_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_rollout",
 )
 
@@ -61,6 +61,19 @@ class Result(C.Structure):
                 ("refined", C.c_uint32), ("reserved", C.c_uint32),
                 ("kernel_ms", C.c_float), ("total_ms", C.c_float),
                 ("trajectory", LevelState * (MAX_DEPTH + 1))]
+
+
+MAX_PLAN_SEGMENTS = 8
+
+
+class Dubins(C.Structure):
+    _fields_ = [("qi", C.c_double * 3), ("param", C.c_double * 3), ("rho", C.c_double),
+                ("type", C.c_int32), ("reserved", C.c_int32),
+                ("speed", C.c_double), ("start_time", C.c_double), ("end_time", C.c_double)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("n_segments", C.c_int32), ("reserved", C.c_int32), ("segments", Dubins * MAX_PLAN_SEGMENTS)]
 
 
 class TreeLevel(C.Structure):
@@ -109,6 +122,8 @@ def load_library(path=None):
     L.mpc_hip_device_winners.argtypes = [vp, C.POINTER(vp)]
     L.mpc_hip_copy_winners.argtypes = [vp, vp]
     L.mpc_hip_combine_shards.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp]
+    L.mpc_hip_upload_problems_from_plans.argtypes = [vp, PP, C.POINTER(u64), C.POINTER(Plan), dp, C.c_uint32]
+    L.mpc_hip_fetch_checkpoints.argtypes = [vp, C.c_uint32, C.POINTER(Checkpoint)]
     L.mpc_hip_set_timing.argtypes = [vp, C.c_uint32]
     L.mpc_hip_timing.argtypes = [vp, i32, C.POINTER(u64), dp, dp]
     L.mpc_hip_solve_tree.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, C.POINTER(TreeLevel), RP]
@@ -230,6 +245,22 @@ class Solver:
         sd = (C.c_uint64 * n)(*seeds) if seeds is not None else None
         _check(self._L.mpc_hip_upload_problems(self._h, arr, sd, n))
         self._n_problems = n
+
+    def upload_from_plans(self, problems, seeds, plans, start_times):
+        """upload(), with every problem's checkpoints sampled on the device from its Dubins plan (binding.Plan) at
+        start_times[p] + 1, 2, ... s; the problems' own checkpoints are ignored."""
+        n = len(problems)
+        arr = (Problem * n)(*problems)
+        sd = (C.c_uint64 * n)(*seeds) if seeds is not None else None
+        pl = (Plan * n)(*plans)
+        t0 = (C.c_double * n)(*[float(t) for t in start_times])
+        _check(self._L.mpc_hip_upload_problems_from_plans(self._h, arr, sd, pl, t0, n))
+        self._n_problems = n
+
+    def fetch_checkpoints(self, problem, depth):
+        out = (Checkpoint * depth)()
+        _check(self._L.mpc_hip_fetch_checkpoints(self._h, int(problem), out))
+        return [(c.x, c.y, c.heading, c.speed) for c in out]
 
     def run_seeded(self, first, count, precision=PREC_FAST, selection=SELECT_LAST_STEP, d_cost_last=None,
                    d_cost_cum=None):

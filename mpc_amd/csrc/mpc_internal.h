@@ -90,6 +90,8 @@ struct mpc_hip_handle {
     bool ran = false;
     std::vector<int32_t> depth, nsub;
 
+    void *d_plans = nullptr; size_t cap_plans = 0;              /* mpc_plan[P] + start times (mpc_plan.hip) */
+
     /* tree search */
     std::vector<TreeLevelBuf> tree;
     uint32_t *d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;

@@ -111,6 +111,20 @@ class DubinsPlan:
         return int((self.start_time() - start_time + self.total_time()) / 1.0 - 1)
 
 
+    def to_struct(self):
+        """-> binding.Plan (mpc_plan of include/mpc_hip.h) for the device-side sampler"""
+        if len(self.wrappers) > B.MAX_PLAN_SEGMENTS:
+            raise B.MpcError(8, "plan has more than MPC_MAX_PLAN_SEGMENTS segments")
+        pl = B.Plan()
+        pl.n_segments = len(self.wrappers)
+        for i, w in enumerate(self.wrappers):
+            d = pl.segments[i]
+            d.qi[:] = w.qi
+            d.param[:] = w.param
+            d.rho, d.type, d.speed, d.start_time, d.end_time = w.rho, w.kind, w.speed, w.start_time, w.end_time
+        return pl
+
+
 def chain(words, rho, speed, start_pose, start_time):
     """Chain Dubins words [(kind, (p0, p1, p2)), ...], each starting at the previous one's end pose/time."""
     plan = DubinsPlan()
@@ -208,10 +222,11 @@ def config1_problem(depth=4, length_m=25.0, current=(0.0, 0.0)):
     return p, plan
 
 
-def fleet_problems(n_problems, depth=20, base_seed=SEED):
-    """Config 5: independent vessels; per problem a random Dubins word, start perturbation and current."""
+def fleet_problems(n_problems, depth=20, base_seed=SEED, with_plans=False):
+    """Config 5: independent vessels; per problem a random Dubins word, start perturbation and current.
+    with_plans: also return the DubinsPlan objects (every plan starts at T0)."""
     rng = np.random.RandomState(base_seed & 0x7FFFFFFF)
-    probs, seeds = [], []
+    probs, seeds, plans = [], [], []
     for i in range(n_problems):
         kind = int(rng.randint(0, 6))
         if kind in (RLR, LRL):
@@ -236,4 +251,5 @@ def fleet_problems(n_problems, depth=20, base_seed=SEED):
                                     last=(float(rng.randint(-8, 9)) * 0.0625, float(rng.randint(0, 9)) * 0.125),
                                     current=(float(cur[0]), float(cur[1]))))
         seeds.append((base_seed + i) & 0xFFFFFFFFFFFFFFFF)
-    return probs, seeds
+        plans.append(plan)
+    return (probs, seeds, plans) if with_plans else (probs, seeds)

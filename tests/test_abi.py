@@ -34,14 +34,16 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_the_header(tmp_path):
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpc_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpc_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(mpc_problem),sizeof(mpc_result),sizeof(mpc_level_state),sizeof(mpc_checkpoint),'
-                   'offsetof(mpc_problem,depth),offsetof(mpc_problem,substeps),offsetof(mpc_result,trajectory),sizeof(mpc_tree_level));return 0;}\n')
+                   'offsetof(mpc_problem,depth),offsetof(mpc_problem,substeps),offsetof(mpc_result,trajectory),sizeof(mpc_tree_level),'
+                   'sizeof(mpc_dubins),sizeof(mpc_plan),offsetof(mpc_dubins,speed));return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(M.Problem), C.sizeof(M.Result), C.sizeof(M.LevelState), C.sizeof(M.Checkpoint),
-            M.Problem.depth.offset, M.Problem.substeps.offset, M.Result.trajectory.offset, C.sizeof(M.TreeLevel)]
+            M.Problem.depth.offset, M.Problem.substeps.offset, M.Result.trajectory.offset, C.sizeof(M.TreeLevel),
+            C.sizeof(M.Dubins), C.sizeof(M.Plan), M.Dubins.speed.offset]
     assert got == want
 
 
@@ -51,6 +53,7 @@ def test_header_is_plain_c_and_constants_agree():
     assert 'extern "C"' in text and "torch" not in code and "std::" not in code and "class " not in code
     assert int(re.search(r"#define MPC_MAX_DEPTH (\d+)", text).group(1)) == M.MAX_DEPTH
     assert int(re.search(r"#define MPC_MAX_SUBSTEPS (\d+)", text).group(1)) == M.MAX_SUBSTEPS
+    assert int(re.search(r"#define MPC_MAX_PLAN_SEGMENTS (\d+)", text).group(1)) == M.binding.MAX_PLAN_SEGMENTS
     assert float(re.search(r"#define MPC_REFINE_REL ([0-9.eE+-]+)", text).group(1)) == M.REFINE_REL
 
 
