@@ -46,12 +46,38 @@ def cpu_baseline(problem, seed, want_ordinal):
         t_total += time.perf_counter() - t0
         reps += 1
     steps = reps * N_CAND * problem.depth * problem.n_substeps
+    # additionally: the same loop on all the host threads this job may use, each on its own slice of
+    # the set -- NOT how the reference runs (one std::async thread, controller.cpp:295), labelled as such
+    from concurrent.futures import ThreadPoolExecutor
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    per = N_CAND // threads
+    def slice_(k):                     # ctypes releases the GIL inside the C call
+        return O.eval_seeded(cfg, veh, cps, problem.depth, sub, seed, k * per, 1, per)[2]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(slice_, range(threads)))
+    t_all = time.perf_counter() - t0
     return {
         "value": steps / t_total, "unit": "steps/s", "cores": 1, "kind": "port",
         "sample": "%d x the full config-2 set (65536 candidates x 400 steps), %.1f s" % (reps, t_total),
         "same_choice_as_gpu": bool(best.best_index == want_ordinal),
         "host_cpus": os.cpu_count(),
+        "all_threads": {"value": threads * per * problem.depth * problem.n_substeps / t_all, "unit": "steps/s",
+                        "cores": threads, "note": "not the reference's behaviour (its solve is single-threaded)"},
     }
+
+
+def measured_valu(k1_seconds):
+    """SURVEY.md 8d's second figure: rocprof-counted VALU instructions x 64 lanes / (kernel time x peak lane-issue
+    rate 256 CU x 4 SIMD x 16 lanes x 2.4 GHz).  The instruction count comes from the committed PMC pass of this
+    command (counters cannot be read inside the timed process), the time is this run's."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        insts = float(prof["sq_insts_valu"])
+    except Exception:
+        return None
+    return {"sq_insts_valu_per_launch": insts, "lane_issue_frac": insts * 64 / (k1_seconds * 256 * 4 * 16 * 2.4e9),
+            "source": "profiles/r01_pmc_summary.json (SQ_INSTS_VALU) / this run's kernel time"}
 
 
 def measured_traffic():
@@ -230,6 +256,7 @@ def main():
                 "unit": "TFLOP/s", "frac": flop / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": measured_traffic() if args.workload == "config2" and prec == M.PREC_FAST else None,
                 "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+                "measured_valu": measured_valu(k1_ms * 1e-3) if args.workload == "config2" and prec == M.PREC_FAST else None,
                 "algorithmic_flop_per_launch": flop, "kernel_steps_per_sec": steps_per_solve / (k1_ms * 1e-3),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,
                         "achieved_GBps": hbm_bytes / (k1_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS},
