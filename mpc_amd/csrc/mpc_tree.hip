@@ -157,71 +157,131 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *
 }
 
 /* ---- expansion: one lane per child ------------------------------------------------------------------------ */
+struct Child { Veh s; double r, t, score, cum; uint32_t parent; };
+
+/* child c of the level whose parents are A: j-th control pair (throttle outer, rudder inner) of parent `par` */
+__device__ inline Child make_child(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
+                                   uint32_t par, uint32_t j, int level)
+{
+    ControlSet cs;
+    control_set(P, A.last_r[par], A.last_t[par], cs);
+    const int ti = (int)(j / (uint32_t)cs.nr), ri = (int)(j % (uint32_t)cs.nr);
+    double r = cs.r[0], t = cs.t[0];
+#pragma unroll
+    for (int q = 1; q < 6; q++) if (q == ri) r = cs.r[q];
+#pragma unroll
+    for (int q = 1; q < 5; q++) if (q == ti) t = cs.t[q];
+    Child ch;
+    ch.s = Veh{A.x[par], A.y[par], A.h[par], A.v[par], A.rpm[par], 0.0, 0.0};
+    strict_level(ch.s, r, t, subL, P.nsub, P.cx, P.cy);                               /* controller.cpp:149-150 */
+    const Weights w{P.wd, P.wh, P.ws};
+    ch.score = strict_score(cpL + level * CP_STRIDE, ch.s, w);                        /* :155 */
+    ch.cum = A.cum[par] + ch.score;                                                   /* :156 */
+    ch.r = r; ch.t = t; ch.parent = par;                                              /* :152-153 (unclamped) */
+    return ch;
+}
+
+__device__ inline void store_child(const LevelPtrs &B, uint32_t at, const Child &ch)
+{
+    B.x[at] = ch.s.x; B.y[at] = ch.s.y; B.h[at] = ch.s.h; B.v[at] = ch.s.v; B.rpm[at] = ch.s.rpm;
+    B.cmg[at] = ch.s.cmg; B.sog[at] = ch.s.sog;
+    B.last_r[at] = ch.r; B.last_t[at] = ch.t; B.cum[at] = ch.cum; B.last_score[at] = ch.score; B.parent[at] = ch.parent;
+}
+
+/* parent of child c = the last node whose offset is <= c (global binary search) */
+__device__ inline uint32_t find_parent(const uint32_t *offset, uint32_t n_parent, uint32_t c)
+{
+    uint32_t lo = 0, hi = n_parent;                     /* invariant: offset[lo] <= c < offset[hi] */
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (offset[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+/* A node has at least 3 x 2 children (controller.cpp:121-146), so the 256 children of a workgroup belong to at most
+ * 44 consecutive parents: ONE lane searches the offsets in global memory (~25 dependent loads on a 2e7-node level),
+ * the workgroup stages a window of offsets in LDS, and every lane finds its parent there. */
+#define PARENT_WINDOW 64
+
+/* STORE = false: the last level of a search -- its nodes will never be parents, so nothing but the workgroup
+ * winners is written (100 B per child saved: 30 GB on a 3e8-leaf level) and no level buffer is needed. */
+template <bool STORE>
 __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                      LevelPtrs B, uint32_t n_child, int level,
                                                      uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord)
 {
-    __shared__ double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[8];
+    __shared__ uint32_t win[PARENT_WINDOW + 1];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
-    stage_problem(P, cpL, subL);
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c0 = blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) win[PARENT_WINDOW] = find_parent(A.offset, n_parent, c0);
+    stage_problem(P, cpL, subL);                                     /* ends with a barrier */
+    const uint32_t par0 = win[PARENT_WINDOW];
+    if (threadIdx.x < PARENT_WINDOW) win[threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
+    __syncthreads();
+    const uint32_t c = c0 + threadIdx.x;
     uint64_t k = ~0ull, o = ~0ull;
     if (c < n_child) {
-        /* parent = last node whose offset <= c */
-        uint32_t lo = 0, hi = n_parent;                 /* invariant: offset[lo] <= c < offset[hi] */
+        uint32_t lo = 0, hi = min((uint32_t)PARENT_WINDOW - 1, n_parent - par0);    /* win[lo] <= c < win[hi] */
         while (hi - lo > 1) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (A.offset[mid] <= c) lo = mid; else hi = mid;
+            const uint32_t mid = (lo + hi) >> 1;
+            if (win[mid] <= c) lo = mid; else hi = mid;
         }
-        const uint32_t par = lo, j = c - A.offset[par];
-        ControlSet cs;
-        const double plr = A.last_r[par], plt = A.last_t[par];
-        control_set(P, plr, plt, cs);
-        const int ti = (int)(j / (uint32_t)cs.nr), ri = (int)(j % (uint32_t)cs.nr);   /* throttle outer, rudder inner */
-        double r = cs.r[0], t = cs.t[0];
-#pragma unroll
-        for (int q = 1; q < 6; q++) if (q == ri) r = cs.r[q];
-#pragma unroll
-        for (int q = 1; q < 5; q++) if (q == ti) t = cs.t[q];
-        Veh s{A.x[par], A.y[par], A.h[par], A.v[par], A.rpm[par], 0.0, 0.0};
-        strict_level(s, r, t, subL, P.nsub, P.cx, P.cy);                              /* controller.cpp:149-150 */
-        const Weights w{P.wd, P.wh, P.ws};
-        const double score = strict_score(cpL + level * CP_STRIDE, s, w);             /* :155 */
-        B.x[c] = s.x; B.y[c] = s.y; B.h[c] = s.h; B.v[c] = s.v; B.rpm[c] = s.rpm; B.cmg[c] = s.cmg; B.sog[c] = s.sog;
-        B.last_r[c] = r; B.last_t[c] = t;                                             /* :152-153 (unclamped) */
-        B.cum[c] = A.cum[par] + score;                                                /* :156 */
-        B.last_score[c] = score;
-        B.parent[c] = par;
-        k = key_of(score); o = c;
+        const Child ch = make_child(P, cpL, subL, A, par0 + lo, c - win[lo], level);
+        if (STORE) store_child(B, c, ch);
+        k = key_of(ch.score); o = c;
     }
     block_argmin(k, o, red);
     if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; }
 }
 
+/* the winner of a level that was expanded without stores: evaluated once more (same code, same bits) into slot 0 of
+ * the level's one-node buffer, where level_reduce_kernel and trace_kernel find it */
+__global__ __launch_bounds__(64) void leaf_record_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
+                                                         LevelPtrs B, int level, const uint64_t *__restrict__ winner)
+{
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    const DevProblem &P = probs[0];
+    stage_problem(P, lds, lds + MPC_MAX_DEPTH * CP_STRIDE);
+    if (threadIdx.x != 0 || winner[1] == ~0ull) return;
+    const uint32_t c = (uint32_t)winner[1];
+    const uint32_t par = find_parent(A.offset, n_parent, c);
+    store_child(B, 0, make_child(P, lds, lds + MPC_MAX_DEPTH * CP_STRIDE, A, par, c - A.offset[par], level));
+}
+
+/* stage 1: (key, ordinal) of the level; stage 2 (a second launch, after leaf_record_kernel where the level was not
+ * stored): the winner's cumulative and last-step score from its record (slot `o`, or slot 0 of a one-node buffer) */
 __global__ __launch_bounds__(256) void level_reduce_kernel(const uint64_t *__restrict__ pkey,
                                                            const uint64_t *__restrict__ pord, uint32_t nblk,
-                                                           LevelPtrs B, uint64_t *__restrict__ out)
+                                                           uint64_t *__restrict__ out)
 {
     __shared__ uint64_t red[8];
     uint64_t k = ~0ull, o = ~0ull;
     for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
     block_argmin(k, o, red);
-    if (threadIdx.x == 0) {
-        out[0] = k; out[1] = o;
-        out[2] = (o != ~0ull) ? (uint64_t)__double_as_longlong(B.cum[o]) : KEY_INF;
-        out[3] = (o != ~0ull) ? (uint64_t)__double_as_longlong(B.last_score[o]) : KEY_INF;
-    }
+    if (threadIdx.x == 0) { out[0] = k; out[1] = o; }
 }
 
+__global__ void level_scores_kernel(LevelPtrs B, int stored, uint64_t *__restrict__ out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const uint64_t o = out[1];
+    const uint64_t at = stored ? o : 0;
+    out[2] = (o != ~0ull) ? (uint64_t)__double_as_longlong(B.cum[at]) : KEY_INF;
+    out[3] = (o != ~0ull) ? (uint64_t)__double_as_longlong(B.last_score[at]) : KEY_INF;
+}
+
+
 /* one launch per level, leaf to root: the cursor (a device word) carries the node index up the parent links */
-__global__ void trace_kernel(LevelPtrs L, int l, int depth, uint32_t leaf, uint32_t *__restrict__ cursor,
+__global__ void trace_kernel(LevelPtrs L, int l, int depth, uint32_t leaf, uint32_t leaf_slot, uint32_t *__restrict__ cursor,
                              DevResult *__restrict__ results)
 {
     if (threadIdx.x || blockIdx.x) return;
     DevResult &R = results[0];
-    const uint32_t i = (l == depth) ? leaf : *cursor;
+    const uint32_t i = (l == depth) ? leaf_slot : *cursor;
     R.traj[l] = mpc_level_state{L.x[i], L.y[i], L.h[i], L.v[i], L.rpm[i], L.cmg[i], L.sog[i],
                                 L.last_r[i], L.last_t[i], L.cum[i]};
     if (l == depth) {
@@ -296,6 +356,7 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
 
     int completed = 0;
     uint64_t best_leaf = 0, steps = 0, evaluated = 0;
+    bool leaf_stored = true;
     for (int it = 0; it < max_levels; it++) {
         if (now && now(now_ctx) >= end_time) break;                       /* controller.cpp:101-103 */
         TreeLevelBuf &A = h->tree[it];
@@ -320,23 +381,32 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
         if (tot[1] != 0 || tot[0] > max_nodes) break;                     /* does not fit: stop like a deadline */
         const uint32_t nchild = tot[0];
         TreeLevelBuf &B = h->tree[it + 1];
-        if (int s = ensure_level(h, B, nchild)) {
+        /* the last level asked for is never a parent level: expanded without stores into a one-node buffer */
+        const bool stored = it + 1 < max_levels;
+        if (int s = ensure_level(h, B, stored ? nchild : 1)) {
             if (s == MPC_ERR_HIP) { (void)hipGetLastError(); break; }     /* out of memory: stop like a deadline */
             return s;
         }
         B.n = nchild;
         const uint32_t nblk = (nchild + 255) / 256;
         if (int s = mpc_ensure_partials(h, nblk)) return s;
-        hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), nchild, it,
-                           h->d_pkey, h->d_pord);
-        hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, ptrs(B),
-                           h->d_winners);
+        if (stored)
+            hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), nchild, it,
+                               h->d_pkey, h->d_pord);
+        else
+            hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), nchild, it,
+                               h->d_pkey, h->d_pord);
+        hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, h->d_winners);
+        if (!stored)
+            hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
+        hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
         completed = it + 1;
         best_leaf = h->h_pair[1];
+        leaf_stored = stored;
         evaluated += nchild;
         steps += (uint64_t)nchild * (uint64_t)h_problem->n_substeps;
         if (h_level_best) {
@@ -355,7 +425,7 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
     }
     for (int l = completed; l >= 0; l--)
         hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(h->tree[l]), l, completed,
-                           (uint32_t)best_leaf, h->d_list_count, h->d_results);
+                           (uint32_t)best_leaf, leaf_stored ? (uint32_t)best_leaf : 0u, h->d_list_count, h->d_results);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], h->stream));
     h->runs++;

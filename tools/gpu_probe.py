@@ -1,7 +1,8 @@
 """perf probe (not a test, not the bench): rollout-kernel time for a library variant / workgroup size.
-usage: python gpu_probe.py [lib.so] ; env MPC_K1_BLOCK overrides the K1 workgroup size"""
+usage: python tools/gpu_probe.py [lib.so]"""
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401  (one HIP runtime per process)
 import mpc_amd as M
 from mpc_amd import binding as B

@@ -1,11 +1,13 @@
 """perf probe (not a test, not the bench): the reference-native tree search at growing depth, GPU vs CPU oracle."""
 import math
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import torch  # noqa: F401
 import mpc_amd as M
 from mpc_amd import workloads as W
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from helpers import oracle_args
 import oracle as O
 

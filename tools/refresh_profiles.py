@@ -40,9 +40,9 @@ with open(os.path.join(out, tag + "_bench_kernel_stats.csv"), "w") as f:
 
 tree = os.path.join(src, "tree", "t_kernel_stats.csv")
 if os.path.exists(tree):
-    extra = ["", "# gpu_probe_tree.py output of the same run:"]
+    extra = ["", "# tools/gpu_probe_tree.py output of the same run:"]
     extra += ["# " + ln.rstrip() for ln in open(os.path.join(src, "tree.log")) if ln.startswith("depth=")]
-    txt, _ = stats_table(tree, "rocprofv3 --kernel-trace --stats --output-format csv -- python3 gpu_probe_tree.py"
+    txt, _ = stats_table(tree, "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/gpu_probe_tree.py"
                                "   (tree search, depths 3..7, strict precision)", extra)
     open(os.path.join(out, tag + "_tree_kernel_stats.txt"), "w").write(txt)
 
