@@ -59,6 +59,12 @@ struct TreeLevelBuf {
     size_t n = 0;
 };
 
+/* device-side view of one TreeLevelBuf */
+struct LevelPtrs {
+    double *x, *y, *h, *v, *rpm, *cmg, *sog, *last_r, *last_t, *cum, *last_score;
+    uint32_t *parent, *count, *offset;
+};
+
 struct mpc_hip_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -95,6 +101,9 @@ struct mpc_hip_handle {
     /* tree search */
     std::vector<TreeLevelBuf> tree;
     uint32_t *d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;
+    uint32_t *d_bpar = nullptr; size_t cap_bpar = 0;              /* first parent of every 256-child workgroup */
+    LevelPtrs *d_level_ptrs = nullptr;                           /* [MPC_MAX_DEPTH + 2], fast-mode path walks */
+    std::vector<LevelPtrs> h_level_ptrs;                         /* its host image (copies are asynchronous) */
     uint64_t *h_pair = nullptr;                                  /* pinned, 4 uint64 */
 };
 

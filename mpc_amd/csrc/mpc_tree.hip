@@ -57,23 +57,20 @@ __device__ inline uint32_t control_count(const DevProblem &P, double last_r, dou
     return (uint32_t)(nr * nt);
 }
 
-struct LevelPtrs {
-    double *x, *y, *h, *v, *rpm, *cmg, *sog, *last_r, *last_t, *cum, *last_score;
-    uint32_t *parent, *count, *offset;
-};
-
 static LevelPtrs ptrs(const TreeLevelBuf &b)
 {
     return LevelPtrs{b.x, b.y, b.h, b.v, b.rpm, b.cmg, b.sog, b.last_r, b.last_t, b.cum, b.last_score,
                      b.parent, b.count, b.offset};
 }
 
-__global__ void root_kernel(const DevProblem *__restrict__ probs, LevelPtrs L)
+/* Node records.  strict: x y h v rpm cmg sog.  fast (MPC_PREC_FAST): x, y through the water, h = sin(heading),
+ * cmg = cos(heading), v, rpm, sog = the last substep's v*dt -- the FastVeh of mpc_model.h in the same arrays. */
+__global__ void root_kernel(const DevProblem *__restrict__ probs, LevelPtrs L, int fast)
 {
     if (threadIdx.x || blockIdx.x) return;
     const DevProblem &P = probs[0];
-    L.x[0] = P.sx; L.y[0] = P.sy; L.h[0] = P.sh; L.v[0] = P.sv; L.rpm[0] = P.srpm;
-    L.cmg[0] = 0; L.sog[0] = 0; L.last_r[0] = P.last_r; L.last_t[0] = P.last_t; L.cum[0] = 0; L.last_score[0] = 0;
+    L.x[0] = P.sx; L.y[0] = P.sy; L.h[0] = fast ? sin(P.sh) : P.sh; L.v[0] = P.sv; L.rpm[0] = P.srpm;
+    L.cmg[0] = fast ? cos(P.sh) : 0; L.sog[0] = 0; L.last_r[0] = P.last_r; L.last_t[0] = P.last_t; L.cum[0] = 0; L.last_score[0] = 0;
     L.parent[0] = 0;
 }
 
@@ -142,9 +139,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_top_kernel(uint32_t *__restri
     }
 }
 
+/* also records, for every 256-child boundary q*256 of the NEXT level, the parent whose child range contains it
+ * (bpar[q]): a node has fewer than 256 children, so each node covers at most one boundary and the expansion
+ * workgroups need no search for their first parent */
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
                                                                 const uint32_t *__restrict__ sums,
-                                                                uint32_t *__restrict__ out)
+                                                                uint32_t *__restrict__ out, uint32_t *__restrict__ bpar)
 {
     __shared__ uint32_t sh[SCAN_BLOCK];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -152,7 +152,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *
     for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? in[base + j] : 0; s += v[j]; }
     uint32_t total;
     uint32_t run = block_exclusive_scan(s, sh, total) + sums[blockIdx.x];
-    for (int j = 0; j < SCAN_ITEMS; j++) { if (base + j < n) out[base + j] = run; run += v[j]; }
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        if (base + j < n) {
+            out[base + j] = run;
+            const uint64_t q = ((uint64_t)run + 255) >> 8;
+            if ((q << 8) < (uint64_t)run + v[j]) bpar[q] = base + j;
+        }
+        run += v[j];
+    }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = sums[gridDim.x];
 }
 
@@ -200,28 +207,27 @@ __device__ inline uint32_t find_parent(const uint32_t *offset, uint32_t n_parent
 }
 
 /* A node has at least 3 x 2 children (controller.cpp:121-146), so the 256 children of a workgroup belong to at most
- * 44 consecutive parents: ONE lane searches the offsets in global memory (~25 dependent loads on a 2e7-node level),
- * the workgroup stages a window of offsets in LDS, and every lane finds its parent there. */
+ * 44 consecutive parents: the first one comes from bpar[] (written by the scan), the workgroup stages a window of
+ * offsets in LDS, and every lane finds its parent there -- no search in global memory (a binary search over a
+ * 2e7-node level is ~25 dependent loads, ten times the workgroup's arithmetic). */
 #define PARENT_WINDOW 64
 
 /* STORE = false: the last level of a search -- its nodes will never be parents, so nothing but the workgroup
  * winners is written (100 B per child saved: 30 GB on a 3e8-leaf level) and no level buffer is needed. */
 template <bool STORE>
 __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
-                                                     LevelPtrs B, uint32_t n_child, int level,
+                                                     const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
                                                      uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[8];
-    __shared__ uint32_t win[PARENT_WINDOW + 1];
+    __shared__ uint32_t win[PARENT_WINDOW];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     const uint32_t c0 = blockIdx.x * blockDim.x;
-    if (threadIdx.x == 0) win[PARENT_WINDOW] = find_parent(A.offset, n_parent, c0);
-    stage_problem(P, cpL, subL);                                     /* ends with a barrier */
-    const uint32_t par0 = win[PARENT_WINDOW];
+    const uint32_t par0 = bpar[blockIdx.x];                          /* the parent of child c0 (scan_apply_kernel) */
     if (threadIdx.x < PARENT_WINDOW) win[threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
-    __syncthreads();
+    stage_problem(P, cpL, subL);                                     /* ends with a barrier */
     const uint32_t c = c0 + threadIdx.x;
     uint64_t k = ~0ull, o = ~0ull;
     if (c < n_child) {
@@ -250,6 +256,218 @@ __global__ __launch_bounds__(64) void leaf_record_kernel(const DevProblem *__res
     const uint32_t c = (uint32_t)winner[1];
     const uint32_t par = find_parent(A.offset, n_parent, c);
     store_child(B, 0, make_child(P, lds, lds + MPC_MAX_DEPTH * CP_STRIDE, A, par, c - A.offset[par], level));
+}
+
+/* ---- fast-model expansion (MPC_PREC_FAST) -------------------------------------------------------------------
+ * The same tree (the control sets depend on controls only, never on states), expanded with the streamlined model
+ * of mpc_model.h (28 instead of ~150 FP64 instructions per substep).  What makes the result the reference's:
+ * every leaf whose fast last-step score is within MPC_REFINE_REL of the level's minimum is re-evaluated along its
+ * whole path from the root with the strict model, the strict (score, ordinal) decides, and the returned trajectory
+ * and scores are the strict path's -- bit for bit what the strict expansion returns for the same leaf. */
+__device__ inline void pick_control(const ControlSet &cs, uint32_t j, double &r, double &t)
+{
+    const int ti = (int)(j / (uint32_t)cs.nr), ri = (int)(j % (uint32_t)cs.nr);      /* throttle outer, rudder inner */
+    r = cs.r[0]; t = cs.t[0];
+#pragma unroll
+    for (int q = 1; q < 6; q++) if (q == ri) r = cs.r[q];
+#pragma unroll
+    for (int q = 1; q < 5; q++) if (q == ti) t = cs.t[q];
+}
+
+struct FastChild { FastVeh s; double r, t, score, cum; uint32_t parent; };
+
+__device__ inline FastChild make_child_fast(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
+                                            uint32_t par, uint32_t j, int level)
+{
+    ControlSet cs;
+    control_set(P, A.last_r[par], A.last_t[par], cs);
+    FastChild ch;
+    pick_control(cs, j, ch.r, ch.t);
+    ch.s.x = A.x[par]; ch.s.y = A.y[par]; ch.s.sh = A.h[par]; ch.s.ch = A.cmg[par]; ch.s.v = A.v[par]; ch.s.rpm = A.rpm[par];
+    ch.s.delta = 0;
+    fast_level<SUB_STRIDE>(ch.s, ch.r, ch.t, subL, P.nsub);
+    const Weights w{P.wd, P.wh, P.ws};
+    ch.score = fast_score(cpL + level * CP_STRIDE, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
+    ch.cum = A.cum[par] + ch.score;
+    ch.parent = par;
+    return ch;
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
+                                                          const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
+                                                          double refine_rel,
+                                                          uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
+                                                          uint32_t *__restrict__ pcnt)
+{
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ uint64_t red[10];
+    __shared__ uint32_t win[PARENT_WINDOW];
+    const DevProblem &P = probs[0];
+    double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    const uint32_t c0 = blockIdx.x * blockDim.x;
+    const uint32_t par0 = bpar[blockIdx.x];                          /* the parent of child c0 (scan_apply_kernel) */
+    if (threadIdx.x < PARENT_WINDOW) win[threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
+    stage_problem(P, cpL, subL);
+    const uint32_t c = c0 + threadIdx.x;
+    uint64_t k = ~0ull, o = ~0ull;
+    double mykey = __longlong_as_double((long long)KEY_INF);
+    if (c < n_child) {
+        uint32_t lo = 0, hi = min((uint32_t)PARENT_WINDOW - 1, n_parent - par0);
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (win[mid] <= c) lo = mid; else hi = mid;
+        }
+        const FastChild ch = make_child_fast(P, cpL, subL, A, par0 + lo, c - win[lo], level);
+        if (STORE) {
+            B.x[c] = ch.s.x; B.y[c] = ch.s.y; B.h[c] = ch.s.sh; B.cmg[c] = ch.s.ch; B.v[c] = ch.s.v; B.rpm[c] = ch.s.rpm;
+            B.sog[c] = ch.s.delta; B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.cum[c] = ch.cum; B.last_score[c] = ch.score;
+            B.parent[c] = ch.parent;
+        }
+        k = key_of(ch.score); o = c;
+        mykey = __longlong_as_double((long long)k);
+    }
+    block_argmin(k, o, red);
+    uint32_t *cnt = (uint32_t *)(red + 9);
+    if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
+    __syncthreads();
+    const double m = __longlong_as_double((long long)red[8]);
+    const uint32_t wave_n = (uint32_t)__popcll(__ballot(c < n_child && mykey <= m + m * refine_rel));
+    if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);
+    __syncthreads();
+    if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; pcnt[blockIdx.x] = *cnt; }
+}
+
+/* controls along the path root -> child c of the level whose parents are levels[L] (n_parent of them) */
+struct PathCtl { double r[MPC_MAX_DEPTH], t[MPC_MAX_DEPTH]; };
+
+__device__ inline void path_controls(const DevProblem &P, const LevelPtrs *levels, int L, uint32_t n_parent, uint32_t c,
+                                     PathCtl &pc)
+{
+    const LevelPtrs A = levels[L];
+    uint32_t node = find_parent(A.offset, n_parent, c);
+    ControlSet cs;
+    control_set(P, A.last_r[node], A.last_t[node], cs);
+    pick_control(cs, c - A.offset[node], pc.r[L], pc.t[L]);
+    for (int l = L; l >= 1; l--) {
+        const LevelPtrs N = levels[l];
+        pc.r[l - 1] = N.last_r[node]; pc.t[l - 1] = N.last_t[node];
+        node = N.parent[node];
+    }
+}
+
+/* the reference's arithmetic along one path: controller.cpp:149-156 for levels 0..L */
+__device__ inline void strict_path(const DevProblem &P, const double *cpL, const double *subL, const PathCtl &pc, int L,
+                                   double &last, double &cum, mpc_level_state *traj)
+{
+    Veh s{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
+    const Weights w{P.wd, P.wh, P.ws};
+    last = 0; cum = 0;
+    if (traj) traj[0] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
+    for (int l = 0; l <= L; l++) {
+        strict_level(s, pc.r[l], pc.t[l], subL, P.nsub, P.cx, P.cy);
+        last = strict_score(cpL + l * CP_STRIDE, s, w);
+        cum += last;
+        if (traj) traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog, pc.r[l], pc.t[l], cum};
+    }
+}
+
+/* one workgroup per level: fast minimum -> near-tie list -> strict decision.  out[0..3] = strict key bits, leaf
+ * ordinal, strict cumulative and last-step score bits; out[4] = 1 if more than LIST_CAP leaves tie (the caller then
+ * repeats the search with the strict expansion). */
+__global__ __launch_bounds__(256) void tree_finish_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
+                                                          int L, uint32_t n_parent, uint32_t n_child, double refine_rel,
+                                                          const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
+                                                          const uint32_t *__restrict__ pcnt, uint32_t nblk,
+                                                          uint64_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ uint64_t s_list[LIST_CAP];
+    __shared__ uint32_t s_blocks[256];
+    __shared__ uint64_t red[8];
+    __shared__ uint64_t s_win[2];
+    __shared__ uint32_t s_n, s_nb;
+    const DevProblem &P = probs[0];
+    double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    if (threadIdx.x == 0) { s_n = 0; s_nb = 0; }
+    stage_problem(P, cpL, subL);
+    uint64_t k = ~0ull, o = ~0ull;
+    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
+    block_argmin(k, o, red);
+    if (threadIdx.x == 0) { s_win[0] = k; s_win[1] = o; }
+    __syncthreads();
+    k = s_win[0]; o = s_win[1];
+    if (k >= KEY_INF) {                                      /* no finite score: nothing selected */
+        if (threadIdx.x == 0) { out[0] = KEY_INF; out[1] = ~0ull; out[2] = KEY_INF; out[3] = KEY_INF; out[4] = 0; }
+        return;
+    }
+    const double m = __longlong_as_double((long long)k);
+    const double limit = m + m * refine_rel;
+    uint32_t overflow = 0;
+    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) {
+        if (__longlong_as_double((long long)pkey[j]) > limit) continue;
+        if (pcnt[j] <= 1) {
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < LIST_CAP) s_list[at] = pord[j];
+        } else {                                             /* several near-ties in one expansion workgroup */
+            const uint32_t at = atomicAdd(&s_nb, 1u);
+            if (at < 256) s_blocks[at] = j;
+        }
+    }
+    __syncthreads();
+    if (s_nb > 256) overflow = 1;
+    /* those workgroups' children once more, a lane per child, to see which of them are near */
+    const LevelPtrs A = levels[L];
+    for (uint32_t b = 0; b < min(s_nb, 256u); b++) {
+        const uint32_t c = s_blocks[b] * 256 + threadIdx.x;
+        if (c < n_child) {
+            const uint32_t par = find_parent(A.offset, n_parent, c);
+            const FastChild ch = make_child_fast(P, cpL, subL, A, par, c - A.offset[par], L);
+            if (ch.score <= limit) {
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at < LIST_CAP) s_list[at] = c;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t n = s_n;
+    if (n > LIST_CAP) { overflow = 1; n = LIST_CAP; }
+    /* the strict model along each listed leaf's path decides, lowest ordinal among equal scores */
+    uint64_t k2 = ~0ull, o2 = ~0ull;
+    double my_last = 0, my_cum = 0;
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+        PathCtl pc;
+        path_controls(P, levels, L, n_parent, (uint32_t)s_list[e], pc);
+        double last, cum;
+        strict_path(P, cpL, subL, pc, L, last, cum, nullptr);
+        const uint64_t ke = key_of(last);
+        if (ke < k2 || (ke == k2 && s_list[e] < o2)) { k2 = ke; o2 = s_list[e]; my_last = last; my_cum = cum; }
+    }
+    const uint64_t mine_k = k2, mine_o = o2;
+    block_argmin(k2, o2, red);
+    if (threadIdx.x == 0) { s_win[0] = k2; s_win[1] = o2; }
+    __syncthreads();
+    if (mine_k == s_win[0] && mine_o == s_win[1] && mine_o != ~0ull) {      /* exactly one lane holds the winner */
+        out[0] = mine_k; out[1] = mine_o;
+        out[2] = (uint64_t)__double_as_longlong(my_cum); out[3] = (uint64_t)__double_as_longlong(my_last);
+        out[4] = overflow;
+    }
+}
+
+/* the winner's trajectory: the strict model along its path (fast mode's replacement for the trace kernels) */
+__global__ __launch_bounds__(64) void path_trace_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
+                                                        int L, uint32_t n_parent, uint32_t leaf, DevResult *__restrict__ results)
+{
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    const DevProblem &P = probs[0];
+    stage_problem(P, lds, lds + MPC_MAX_DEPTH * CP_STRIDE);
+    if (threadIdx.x != 0) return;
+    DevResult &R = results[0];
+    PathCtl pc;
+    path_controls(P, levels, L, n_parent, leaf, pc);
+    double last, cum;
+    strict_path(P, lds, lds + MPC_MAX_DEPTH * CP_STRIDE, pc, L, last, cum, R.traj);
+    R.best_last = last; R.best_cum = cum; R.key_bits = key_of(last); R.ordinal = leaf; R.refined = 0; R.overflow = 0;
 }
 
 /* stage 1: (key, ordinal) of the level; stage 2 (a second launch, after leaf_record_kernel where the level was not
@@ -305,6 +523,8 @@ void mpc_tree_free(mpc_hip_handle *h)
     for (auto &b : h->tree) free_level(b);
     h->tree.clear();
     (void)hipFree(h->d_scan_tmp); h->d_scan_tmp = nullptr; h->cap_scan_tmp = 0;
+    (void)hipFree(h->d_level_ptrs); h->d_level_ptrs = nullptr;
+    (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
 }
 
 static int ensure_level(mpc_hip_handle *h, TreeLevelBuf &b, size_t n)
@@ -324,39 +544,40 @@ static int ensure_level(mpc_hip_handle *h, TreeLevelBuf &b, size_t n)
     return MPC_OK;
 }
 
-extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
-                                  mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
-                                  mpc_tree_level *h_level_best, mpc_result *h_result)
+static int publish_level(mpc_hip_handle *h, int l)
 {
-    if (!h || !h_problem || !h_result) { mpc_set_err("solve_tree: NULL argument"); return MPC_ERR_INVALID; }
-    if (precision != MPC_PREC_F64) {
-        mpc_set_err("solve_tree evaluates with MPC_PREC_F64 (the reference's arithmetic) only");
-        return MPC_ERR_INVALID;
-    }
-    if (int s = mpc_check_problem(h_problem, precision)) return s;
-    if (max_levels > h_problem->depth) { mpc_set_err("solve_tree: max_levels exceeds the checkpoints supplied"); return MPC_ERR_INVALID; }
-    if (int s = mpc_use_device(h)) return s;
+    h->h_level_ptrs[l] = ptrs(h->tree[l]);
+    HIP_TRY(hipMemcpyAsync(h->d_level_ptrs + l, &h->h_level_ptrs[l], sizeof(LevelPtrs), hipMemcpyHostToDevice, h->stream));
+    return MPC_OK;
+}
+
+static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
+                           mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
+                           mpc_tree_level *h_level_best, mpc_result *h_result)
+{
+    const bool fast = precision == MPC_PREC_FAST;
     memset(h_result, 0, sizeof *h_result);
-    if (max_levels <= 0) {                        /* controller.cpp:80 never entered -> :196 */
-        h_result->status = MPC_ERR_NO_ITERATION;
-        return MPC_ERR_NO_ITERATION;
-    }
     if (max_nodes == 0) max_nodes = 1ull << 28;
     if (max_nodes > 0xFFFFFFF0ull) max_nodes = 0xFFFFFFF0ull;
     if (int s = mpc_hip_upload_problems(h, h_problem, nullptr, 1)) return s;
     if ((int)h->tree.size() < max_levels + 1) h->tree.resize(max_levels + 1);
+    if (!h->d_level_ptrs) {
+        HIP_TRY(hipMalloc(&h->d_level_ptrs, sizeof(LevelPtrs) * (MPC_MAX_DEPTH + 2)));
+        h->h_level_ptrs.assign(MPC_MAX_DEPTH + 2, LevelPtrs{});
+    }
 
     hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
     h->timed[h->runs % TIMING_RING] = 1;
     HIP_TRY(hipEventRecord(ev[0], h->stream));
     if (int s = ensure_level(h, h->tree[0], 1)) return s;
     h->tree[0].n = 1;
-    hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]));
+    hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]), (int)fast);
     HIP_TRY(hipGetLastError());
+    if (int s = publish_level(h, 0)) return s;
 
     int completed = 0;
     uint64_t best_leaf = 0, steps = 0, evaluated = 0;
-    bool leaf_stored = true;
+    bool leaf_stored = true, overflow = false;
     for (int it = 0; it < max_levels; it++) {
         if (now && now(now_ctx) >= end_time) break;                       /* controller.cpp:101-103 */
         TreeLevelBuf &A = h->tree[it];
@@ -372,7 +593,14 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
         hipLaunchKernelGGL(count_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, A.count, n, h->d_scan_tmp);
         hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->d_scan_tmp, ntile);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, A.count, n, h->d_scan_tmp, A.offset);
+        const size_t nbound = (size_t)n * 30 / 256 + 2;                    /* <= 30 children per node (6 x 5) */
+        if (nbound > h->cap_bpar) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
+            HIP_TRY(hipMalloc(&h->d_bpar, sizeof(uint32_t) * nbound));
+            h->cap_bpar = nbound;
+        }
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, A.count, n, h->d_scan_tmp, A.offset, h->d_bpar);
         HIP_TRY(hipGetLastError());
         uint32_t tot[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_scan_tmp + ntile, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, h->stream));
@@ -381,28 +609,42 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
         if (tot[1] != 0 || tot[0] > max_nodes) break;                     /* does not fit: stop like a deadline */
         const uint32_t nchild = tot[0];
         TreeLevelBuf &B = h->tree[it + 1];
-        /* the last level asked for is never a parent level: expanded without stores into a one-node buffer */
+        /* the last level asked for is never a parent level: expanded without stores (strict: into a one-node buffer
+         * that receives the winner's record; fast: the winner comes from its path) */
         const bool stored = it + 1 < max_levels;
         if (int s = ensure_level(h, B, stored ? nchild : 1)) {
             if (s == MPC_ERR_HIP) { (void)hipGetLastError(); break; }     /* out of memory: stop like a deadline */
             return s;
         }
         B.n = nchild;
+        if (int s = publish_level(h, it + 1)) return s;
         const uint32_t nblk = (nchild + 255) / 256;
         if (int s = mpc_ensure_partials(h, nblk)) return s;
-        if (stored)
-            hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), nchild, it,
-                               h->d_pkey, h->d_pord);
-        else
-            hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), nchild, it,
-                               h->d_pkey, h->d_pord);
-        hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, h->d_winners);
-        if (!stored)
-            hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
-        hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);
+        if (fast) {
+            if (stored)
+                hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
+                                   nchild, it, (double)MPC_REFINE_REL, h->d_pkey, h->d_pord, h->d_pcnt);
+            else
+                hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
+                                   nchild, it, (double)MPC_REFINE_REL, h->d_pkey, h->d_pord, h->d_pcnt);
+            hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
+                               (double)MPC_REFINE_REL, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_winners);
+        } else {
+            if (stored)
+                hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
+                                   h->d_pkey, h->d_pord);
+            else
+                hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
+                                   h->d_pkey, h->d_pord);
+            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, h->d_winners);
+            if (!stored)
+                hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
+            hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);
+        }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * (fast ? 5 : 4), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if (fast && h->h_pair[4]) { overflow = true; break; }            /* > LIST_CAP tied leaves: the strict expansion decides */
         if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
         completed = it + 1;
         best_leaf = h->h_pair[1];
@@ -417,15 +659,25 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
         }
     }
     HIP_TRY(hipEventRecord(ev[1], h->stream));
-    if (completed == 0) {
+    if (overflow) {
+        HIP_TRY(hipEventRecord(ev[3], h->stream));
+        h->runs++;
+        return MPC_INTERNAL_RERUN_STRICT;
+    }
+    if (completed == 0 || best_leaf == ~0ull) {
         HIP_TRY(hipEventRecord(ev[3], h->stream));
         h->runs++;
         h_result->status = MPC_ERR_NO_ITERATION;                          /* controller.cpp:196 */
         return MPC_ERR_NO_ITERATION;
     }
-    for (int l = completed; l >= 0; l--)
-        hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(h->tree[l]), l, completed,
-                           (uint32_t)best_leaf, leaf_stored ? (uint32_t)best_leaf : 0u, h->d_list_count, h->d_results);
+    if (fast) {
+        hipLaunchKernelGGL(path_trace_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, h->d_level_ptrs, completed - 1,
+                           (uint32_t)h->tree[completed - 1].n, (uint32_t)best_leaf, h->d_results);
+    } else {
+        for (int l = completed; l >= 0; l--)
+            hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(h->tree[l]), l, completed,
+                               (uint32_t)best_leaf, leaf_stored ? (uint32_t)best_leaf : 0u, h->d_list_count, h->d_results);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], h->stream));
     h->runs++;
@@ -449,4 +701,30 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
     }
     h->ran = false;
     return MPC_OK;
+}
+
+extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
+                                  mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
+                                  mpc_tree_level *h_level_best, mpc_result *h_result)
+{
+    if (!h || !h_problem || !h_result) { mpc_set_err("solve_tree: NULL argument"); return MPC_ERR_INVALID; }
+    if (precision != MPC_PREC_F64 && precision != MPC_PREC_FAST) { mpc_set_err("unknown precision"); return MPC_ERR_INVALID; }
+    if (int s = mpc_check_problem(h_problem, precision)) return s;
+    if (max_levels > h_problem->depth) { mpc_set_err("solve_tree: max_levels exceeds the checkpoints supplied"); return MPC_ERR_INVALID; }
+    if (precision == MPC_PREC_FAST)
+        for (int s = 0; s < h_problem->n_substeps; s++)
+            if (h_problem->substeps[s] > 0.1000001) {
+                mpc_set_err("MPC_PREC_FAST needs substeps <= 0.1 s (VehicleState.h:50); use MPC_PREC_F64");
+                return MPC_ERR_INVALID;
+            }
+    if (int s = mpc_use_device(h)) return s;
+    if (max_levels <= 0) {                        /* controller.cpp:80 never entered -> :196 */
+        memset(h_result, 0, sizeof *h_result);
+        h_result->status = MPC_ERR_NO_ITERATION;
+        return MPC_ERR_NO_ITERATION;
+    }
+    int s = solve_tree_once(h, h_problem, max_levels, precision, now, now_ctx, end_time, max_nodes, h_level_best, h_result);
+    if (s == MPC_INTERNAL_RERUN_STRICT)
+        s = solve_tree_once(h, h_problem, max_levels, MPC_PREC_F64, now, now_ctx, end_time, max_nodes, h_level_best, h_result);
+    return s;
 }

@@ -23,13 +23,13 @@ def _oracle_tree(p, max_levels, budget=-1):
     return O.mpc_tree(cfg, start, cps, max_levels, budget)
 
 
-def _check(solver, p, max_levels):
-    res, levels = solver.solve_tree(p, max_levels)
+def _check_one(solver, p, max_levels, prec):
+    res, levels = solver.solve_tree(p, max_levels, precision=prec)
     it, traj, olev, nodes = _oracle_tree(p, max_levels)
     assert res.status == 0 and res.levels == it == max_levels
     for l in range(it):
         assert levels[l].n_leaves == olev[l].n_leaves, l
-        assert levels[l].best_leaf == olev[l].best_leaf, l
+        assert levels[l].best_leaf == olev[l].best_leaf, (prec, l)
         assert rel_err(levels[l].best_score, olev[l].best_score) <= TOL
         assert rel_err(levels[l].best_cumulative, olev[l].best_cumulative) <= TOL
     got = traj_array(res)
@@ -42,6 +42,18 @@ def _check(solver, p, max_levels):
             assert rel_err(got[l, 5:7], [traj[l].v.cmg, traj[l].v.sog]).max() <= 1e-10
     assert res.first_rudder == traj[1].last_rudder and res.first_throttle == traj[1].last_throttle
     assert res.evaluated == sum(olev[l].n_leaves for l in range(it))
+    return res, levels
+
+
+def _check(solver, p, max_levels):
+    """strict expansion, then the fast expansion (streamlined model + strict decision among near-tied leaves + the
+    winner's strict path): the same leaf at every level and bit-identical scores and trajectory"""
+    res, levels = _check_one(solver, p, max_levels, M.PREC_F64)
+    fres, flevels = _check_one(solver, p, max_levels, M.PREC_FAST)
+    assert traj_array(fres).tobytes() == traj_array(res).tobytes()
+    assert (fres.best_ordinal, fres.best_last, fres.best_cumulative) == (res.best_ordinal, res.best_last, res.best_cumulative)
+    for a, b in zip(flevels[:max_levels], levels[:max_levels]):
+        assert (a.n_leaves, a.best_leaf, a.best_score, a.best_cumulative) == (b.n_leaves, b.best_leaf, b.best_score, b.best_cumulative)
     return res
 
 

@@ -14,16 +14,17 @@ import oracle as O
 s = M.Solver(0)
 w = W.DubinsWrapper((0.0, 0.0, math.pi / 2), (0.0, math.pi, 0.0), 8.0, W.LRL, 2.5, 4.0)
 plan = W.DubinsPlan([w])
+PREC = M.PREC_FAST if len(sys.argv) > 1 and sys.argv[1] == "fast" else M.PREC_F64
 for depth in (3, 4, 5, 6, 7):
     p = M.make_problem((0.0, 0.0, 0.0, 2.5), plan.checkpoints(4.0, depth), M.substep_schedule(1.0), current=(0.2, -0.1))
     for rep in range(3):
         t0 = time.perf_counter()
         try:
-            res, lv = s.solve_tree(p, depth, max_nodes=1 << 30)
+            res, lv = s.solve_tree(p, depth, precision=PREC, max_nodes=1 << 30)
         except M.MpcError as e:
             print("depth", depth, "failed:", e); break
         wall = (time.perf_counter() - t0) * 1e3
-    line = "depth=%d levels=%d leaves=%s evaluated=%d gpu_ms=%.3f wall_ms=%.3f steps/s=%.3e first=(%g,%g)" % (
+    line = ("fast " if PREC == M.PREC_FAST else "") + "depth=%d levels=%d leaves=%s evaluated=%d gpu_ms=%.3f wall_ms=%.3f steps/s=%.3e first=(%g,%g)" % (
         depth, res.levels, [int(lv[i].n_leaves) for i in range(res.levels)][-1], res.evaluated, res.total_ms, wall,
         res.rollout_steps / (res.total_ms * 1e-3), res.first_rudder, res.first_throttle)
     if depth <= 5:
