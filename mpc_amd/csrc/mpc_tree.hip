@@ -17,28 +17,39 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "mpc_internal.h"
 
 using namespace mpc;
 
 /* ---- control sets, controller.cpp:121-146 --------------------------------------------------------------- */
-struct ControlSet { double r[6], t[5]; int nr, nt; };
-
-__device__ inline void control_set(const DevProblem &P, double last_r, double last_t, ControlSet &c)
+/* the j-th control pair of that set (throttle outer, rudder inner, controller.cpp:174-182) without building the
+ * arrays: indexing cs.r[] / cs.t[] with run-time subscripts puts them in scratch memory, and the expansion then
+ * spends more time on scratch traffic than on the model */
+__device__ inline void control_pick(const DevProblem &P, double last_r, double last_t, uint32_t j, double &r, double &t)
 {
     const double tol = P.tol;
-    int nr = 0, nt = 0;
-    c.r[nr++] = P.minr; c.r[nr++] = P.midr; c.r[nr++] = P.maxr;
-    c.t[nt++] = P.mint; c.t[nt++] = P.maxt;
     const double low_r = last_r - P.gr, high_r = last_r + P.gr;
-    if (P.minr + tol < low_r && fabs(P.midr - low_r) > tol) c.r[nr++] = low_r;
-    if (fabs(P.midr - high_r) > tol && P.maxr > high_r + tol) c.r[nr++] = high_r;
-    if (fabs(P.minr - last_r) > tol && fabs(P.midr - last_r) > tol && fabs(P.maxr - last_r) > tol) c.r[nr++] = last_r;
+    const bool r3 = P.minr + tol < low_r && fabs(P.midr - low_r) > tol;
+    const bool r4 = fabs(P.midr - high_r) > tol && P.maxr > high_r + tol;
+    const bool r5 = fabs(P.minr - last_r) > tol && fabs(P.midr - last_r) > tol && fabs(P.maxr - last_r) > tol;
     const double low_t = last_t - P.gt, high_t = last_t + P.gt;
-    if (P.mint + tol < low_t) c.t[nt++] = low_t;
-    if (P.maxt > high_t + tol) c.t[nt++] = high_t;
-    if (fabs(P.mint - last_t) > tol && fabs(P.maxt - last_t) > tol) c.t[nt++] = last_t;
-    c.nr = nr; c.nt = nt;
+    const bool t2 = P.mint + tol < low_t;
+    const bool t3 = P.maxt > high_t + tol;
+    const bool t4 = fabs(P.mint - last_t) > tol && fabs(P.maxt - last_t) > tol;
+    const uint32_t nr = 3u + r3 + r4 + r5;
+    const uint32_t ti = j / nr, ri = j - ti * nr;
+    r = ri == 0 ? P.minr : (ri == 1 ? P.midr : P.maxr);
+    int k = (int)ri - 3;                                   /* k-th of the optional rudders that are present */
+    if (r3) { if (k == 0) r = low_r; k--; }
+    if (r4) { if (k == 0) r = high_r; k--; }
+    if (r5) { if (k == 0) r = last_r; }
+    t = ti == 0 ? P.mint : P.maxt;
+    k = (int)ti - 2;
+    if (t2) { if (k == 0) t = low_t; k--; }
+    if (t3) { if (k == 0) t = high_t; k--; }
+    if (t4) { if (k == 0) t = last_t; }
 }
 
 /* only the counts (same predicates) */
@@ -170,14 +181,8 @@ struct Child { Veh s; double r, t, score, cum; uint32_t parent; };
 __device__ inline Child make_child(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
                                    uint32_t par, uint32_t j, int level)
 {
-    ControlSet cs;
-    control_set(P, A.last_r[par], A.last_t[par], cs);
-    const int ti = (int)(j / (uint32_t)cs.nr), ri = (int)(j % (uint32_t)cs.nr);
-    double r = cs.r[0], t = cs.t[0];
-#pragma unroll
-    for (int q = 1; q < 6; q++) if (q == ri) r = cs.r[q];
-#pragma unroll
-    for (int q = 1; q < 5; q++) if (q == ti) t = cs.t[q];
+    double r, t;
+    control_pick(P, A.last_r[par], A.last_t[par], j, r, t);
     Child ch;
     ch.s = Veh{A.x[par], A.y[par], A.h[par], A.v[par], A.rpm[par], 0.0, 0.0};
     strict_level(ch.s, r, t, subL, P.nsub, P.cx, P.cy);                               /* controller.cpp:149-150 */
@@ -214,31 +219,60 @@ __device__ inline uint32_t find_parent(const uint32_t *offset, uint32_t n_parent
 
 /* STORE = false: the last level of a search -- its nodes will never be parents, so nothing but the workgroup
  * winners is written (100 B per child saved: 30 GB on a 3e8-leaf level) and no level buffer is needed. */
+/* A workgroup expands tpb <= EXPAND_TILES consecutive tiles of 256 children: the problem is staged once per
+ * workgroup (a 256-child workgroup spent more time in its prologue's memory latencies than on the model: 12.9 ->
+ * 8.5 ms on a 3e8-leaf level), and the next tile's offset window is fetched while the current tile computes.  The
+ * host picks tpb = 1 while a level has too few tiles to fill the chip. */
+#define EXPAND_TILES 8
+
+__device__ inline uint32_t window_parent(const uint32_t *win, uint32_t par0, uint32_t n_parent, uint32_t c, uint32_t &first)
+{
+    uint32_t lo = 0, hi = min((uint32_t)PARENT_WINDOW - 1, n_parent - par0);          /* win[lo] <= c < win[hi] */
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (win[mid] <= c) lo = mid; else hi = mid;
+    }
+    first = win[lo];
+    return par0 + lo;
+}
+
 template <bool STORE>
 __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                      const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
-                                                     uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord)
+                                                     uint32_t tpb, uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[8];
-    __shared__ uint32_t win[PARENT_WINDOW];
+    __shared__ uint32_t win[2][PARENT_WINDOW];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
-    const uint32_t c0 = blockIdx.x * blockDim.x;
-    const uint32_t par0 = bpar[blockIdx.x];                          /* the parent of child c0 (scan_apply_kernel) */
-    if (threadIdx.x < PARENT_WINDOW) win[threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
+    const uint32_t n_tiles = (n_child + 255) / 256;
+    const uint32_t tile0 = blockIdx.x * tpb;
+    uint32_t par0 = bpar[tile0];                                     /* the parent of the tile's first child (scan_apply_kernel) */
+    if (threadIdx.x < PARENT_WINDOW) win[0][threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
     stage_problem(P, cpL, subL);                                     /* ends with a barrier */
-    const uint32_t c = c0 + threadIdx.x;
     uint64_t k = ~0ull, o = ~0ull;
-    if (c < n_child) {
-        uint32_t lo = 0, hi = min((uint32_t)PARENT_WINDOW - 1, n_parent - par0);    /* win[lo] <= c < win[hi] */
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (win[mid] <= c) lo = mid; else hi = mid;
+    for (uint32_t i = 0; i < tpb && tile0 + i < n_tiles; i++) {
+        const uint32_t tile = tile0 + i;
+        const bool more = i + 1 < tpb && tile + 1 < n_tiles;
+        uint32_t par_next = 0, off_next = 0;
+        if (more) {                                                   /* in flight during this tile's arithmetic */
+            par_next = bpar[tile + 1];
+            if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[min(par_next + threadIdx.x, n_parent)];
         }
-        const Child ch = make_child(P, cpL, subL, A, par0 + lo, c - win[lo], level);
-        if (STORE) store_child(B, c, ch);
-        k = key_of(ch.score); o = c;
+        const uint32_t c = tile * 256 + threadIdx.x;
+        if (c < n_child) {
+            uint32_t first;
+            const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
+            const Child ch = make_child(P, cpL, subL, A, par, c - first, level);
+            if (STORE) store_child(B, c, ch);
+            lex_min(k, o, key_of(ch.score), (uint64_t)c);
+        }
+        if (more) {
+            if (threadIdx.x < PARENT_WINDOW) win[(i + 1) & 1][threadIdx.x] = off_next;
+            par0 = par_next;
+            __syncthreads();
+        }
     }
     block_argmin(k, o, red);
     if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; }
@@ -264,25 +298,13 @@ __global__ __launch_bounds__(64) void leaf_record_kernel(const DevProblem *__res
  * every leaf whose fast last-step score is within MPC_REFINE_REL of the level's minimum is re-evaluated along its
  * whole path from the root with the strict model, the strict (score, ordinal) decides, and the returned trajectory
  * and scores are the strict path's -- bit for bit what the strict expansion returns for the same leaf. */
-__device__ inline void pick_control(const ControlSet &cs, uint32_t j, double &r, double &t)
-{
-    const int ti = (int)(j / (uint32_t)cs.nr), ri = (int)(j % (uint32_t)cs.nr);      /* throttle outer, rudder inner */
-    r = cs.r[0]; t = cs.t[0];
-#pragma unroll
-    for (int q = 1; q < 6; q++) if (q == ri) r = cs.r[q];
-#pragma unroll
-    for (int q = 1; q < 5; q++) if (q == ti) t = cs.t[q];
-}
-
 struct FastChild { FastVeh s; double r, t, score, cum; uint32_t parent; };
 
 __device__ inline FastChild make_child_fast(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
                                             uint32_t par, uint32_t j, int level)
 {
-    ControlSet cs;
-    control_set(P, A.last_r[par], A.last_t[par], cs);
     FastChild ch;
-    pick_control(cs, j, ch.r, ch.t);
+    control_pick(P, A.last_r[par], A.last_t[par], j, ch.r, ch.t);
     ch.s.x = A.x[par]; ch.s.y = A.y[par]; ch.s.sh = A.h[par]; ch.s.ch = A.cmg[par]; ch.s.v = A.v[par]; ch.s.rpm = A.rpm[par];
     ch.s.delta = 0;
     fast_level<SUB_STRIDE>(ch.s, ch.r, ch.t, subL, P.nsub);
@@ -296,44 +318,66 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
 template <bool STORE>
 __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                           const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
-                                                          double refine_rel,
+                                                          double refine_rel, uint32_t tpb,
                                                           uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
                                                           uint32_t *__restrict__ pcnt)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
-    __shared__ uint32_t win[PARENT_WINDOW];
+    __shared__ uint32_t win[2][PARENT_WINDOW];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
-    const uint32_t c0 = blockIdx.x * blockDim.x;
-    const uint32_t par0 = bpar[blockIdx.x];                          /* the parent of child c0 (scan_apply_kernel) */
-    if (threadIdx.x < PARENT_WINDOW) win[threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
+    const uint32_t n_tiles = (n_child + 255) / 256;
+    const uint32_t tile0 = blockIdx.x * tpb;
+    uint32_t par0 = bpar[tile0];
+    if (threadIdx.x < PARENT_WINDOW) win[0][threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
     stage_problem(P, cpL, subL);
-    const uint32_t c = c0 + threadIdx.x;
     uint64_t k = ~0ull, o = ~0ull;
-    double mykey = __longlong_as_double((long long)KEY_INF);
-    if (c < n_child) {
-        uint32_t lo = 0, hi = min((uint32_t)PARENT_WINDOW - 1, n_parent - par0);
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (win[mid] <= c) lo = mid; else hi = mid;
+    double keys[EXPAND_TILES];                                         /* this lane's scores, for the near-tie count */
+#pragma unroll
+    for (uint32_t i = 0; i < EXPAND_TILES; i++) {
+        keys[i] = __longlong_as_double((long long)KEY_INF);
+        const uint32_t tile = tile0 + i;
+        if (i < tpb && tile < n_tiles) {                               /* uniform */
+            const bool more = i + 1 < tpb && tile + 1 < n_tiles;
+            uint32_t par_next = 0, off_next = 0;
+            if (more) {
+                par_next = bpar[tile + 1];
+                if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[min(par_next + threadIdx.x, n_parent)];
+            }
+            const uint32_t c = tile * 256 + threadIdx.x;
+            if (c < n_child) {
+                uint32_t first;
+                const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
+                const FastChild ch = make_child_fast(P, cpL, subL, A, par, c - first, level);
+                if (STORE) {
+                    B.x[c] = ch.s.x; B.y[c] = ch.s.y; B.h[c] = ch.s.sh; B.cmg[c] = ch.s.ch; B.v[c] = ch.s.v; B.rpm[c] = ch.s.rpm;
+                    B.sog[c] = ch.s.delta; B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.cum[c] = ch.cum; B.last_score[c] = ch.score;
+                    B.parent[c] = ch.parent;
+                }
+                const uint64_t kc = key_of(ch.score);
+                keys[i] = __longlong_as_double((long long)kc);
+                lex_min(k, o, kc, (uint64_t)c);
+            }
+            if (more) {
+                if (threadIdx.x < PARENT_WINDOW) win[(i + 1) & 1][threadIdx.x] = off_next;
+                par0 = par_next;
+                __syncthreads();
+            }
         }
-        const FastChild ch = make_child_fast(P, cpL, subL, A, par0 + lo, c - win[lo], level);
-        if (STORE) {
-            B.x[c] = ch.s.x; B.y[c] = ch.s.y; B.h[c] = ch.s.sh; B.cmg[c] = ch.s.ch; B.v[c] = ch.s.v; B.rpm[c] = ch.s.rpm;
-            B.sog[c] = ch.s.delta; B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.cum[c] = ch.cum; B.last_score[c] = ch.score;
-            B.parent[c] = ch.parent;
-        }
-        k = key_of(ch.score); o = c;
-        mykey = __longlong_as_double((long long)k);
     }
     block_argmin(k, o, red);
+    /* how many of this workgroup's children lie within refine_rel of ITS minimum (a superset test for the level's) */
     uint32_t *cnt = (uint32_t *)(red + 9);
     if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
     __syncthreads();
     const double m = __longlong_as_double((long long)red[8]);
-    const uint32_t wave_n = (uint32_t)__popcll(__ballot(c < n_child && mykey <= m + m * refine_rel));
-    if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);
+    const double limit = m + m * refine_rel;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < EXPAND_TILES; i++) mine += keys[i] <= limit && keys[i] < __longlong_as_double((long long)KEY_INF);
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(cnt, mine);
     __syncthreads();
     if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; pcnt[blockIdx.x] = *cnt; }
 }
@@ -346,9 +390,7 @@ __device__ inline void path_controls(const DevProblem &P, const LevelPtrs *level
 {
     const LevelPtrs A = levels[L];
     uint32_t node = find_parent(A.offset, n_parent, c);
-    ControlSet cs;
-    control_set(P, A.last_r[node], A.last_t[node], cs);
-    pick_control(cs, c - A.offset[node], pc.r[L], pc.t[L]);
+    control_pick(P, A.last_r[node], A.last_t[node], c - A.offset[node], pc.r[L], pc.t[L]);
     for (int l = L; l >= 1; l--) {
         const LevelPtrs N = levels[l];
         pc.r[l - 1] = N.last_r[node]; pc.t[l - 1] = N.last_t[node];
@@ -376,7 +418,7 @@ __device__ inline void strict_path(const DevProblem &P, const double *cpL, const
  * ordinal, strict cumulative and last-step score bits; out[4] = 1 if more than LIST_CAP leaves tie (the caller then
  * repeats the search with the strict expansion). */
 __global__ __launch_bounds__(256) void tree_finish_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
-                                                          int L, uint32_t n_parent, uint32_t n_child, double refine_rel,
+                                                          int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
                                                           const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
                                                           const uint32_t *__restrict__ pcnt, uint32_t nblk,
                                                           uint64_t *__restrict__ out)
@@ -418,8 +460,8 @@ __global__ __launch_bounds__(256) void tree_finish_kernel(const DevProblem *__re
     if (s_nb > 256) overflow = 1;
     /* those workgroups' children once more, a lane per child, to see which of them are near */
     const LevelPtrs A = levels[L];
-    for (uint32_t b = 0; b < min(s_nb, 256u); b++) {
-        const uint32_t c = s_blocks[b] * 256 + threadIdx.x;
+    for (uint32_t b = 0; b < min(s_nb, 256u) * tpb; b++) {
+        const uint32_t c = (s_blocks[b / tpb] * tpb + b % tpb) * 256 + threadIdx.x;
         if (c < n_child) {
             const uint32_t par = find_parent(A.offset, n_parent, c);
             const FastChild ch = make_child_fast(P, cpL, subL, A, par, c - A.offset[par], L);
@@ -618,24 +660,26 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         }
         B.n = nchild;
         if (int s = publish_level(h, it + 1)) return s;
-        const uint32_t nblk = (nchild + 255) / 256;
+        const uint32_t n_tiles = (nchild + 255) / 256;
+        const uint32_t tpb = std::min<uint32_t>(EXPAND_TILES, std::max<uint32_t>(1, n_tiles / 4096));   /* >= 4096 workgroups first */
+        const uint32_t nblk = (n_tiles + tpb - 1) / tpb;
         if (int s = mpc_ensure_partials(h, nblk)) return s;
         if (fast) {
             if (stored)
                 hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, h->d_pkey, h->d_pord, h->d_pcnt);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt);
             else
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, h->d_pkey, h->d_pord, h->d_pcnt);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt);
             hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
-                               (double)MPC_REFINE_REL, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_winners);
+                               (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_winners);
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   h->d_pkey, h->d_pord);
+                                   tpb, h->d_pkey, h->d_pord);
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   h->d_pkey, h->d_pord);
+                                   tpb, h->d_pkey, h->d_pord);
             hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, h->d_winners);
             if (!stored)
                 hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);

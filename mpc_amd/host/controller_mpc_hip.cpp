@@ -11,7 +11,7 @@
  *                                                        last controls (the reference re-reads the weights per node)
  *   :59-61  maxIterations                                same expression
  *   :96-98  sample the plan per deepening iteration      all maxIterations checkpoints sampled up front
- *   :80-189 iterative-deepening DFS                      mpc_hip_solve_tree (level-synchronous, strict FP64)
+ *   :80-189 iterative-deepening DFS                      mpc_hip_solve_tree (level-synchronous)
  *   :83     cancellation poll per iteration              polled in the time callback, between levels
  *   :101    deadline poll per node                       polled between levels through the same callback
  *   :196-204 cleanup, displayTrajectory, finite check    same
