@@ -234,6 +234,19 @@ int         mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, 
                                int precision, mpc_time_fn now, void *now_ctx, double end_time,
                                uint64_t max_nodes, mpc_tree_level *h_level_best, mpc_result *h_result);
 
+/* One GPU's share of a tree search split over n_shards GPUs.  Every shard expands levels
+ * 1..split_level in full (<= 30^split_level nodes: redundant and cheap); from there shard s keeps the s-th contiguous
+ * slice of the split level's nodes and expands only their subtrees, so DFS order is preserved within and across
+ * shards.  h_level_best[l] for l < split_level is the full level's winner (the same on every shard); for deeper levels
+ * n_leaves counts this shard's leaves and best_leaf is LOCAL to them: the global DFS ordinal is best_leaf + the leaves
+ * of the lower shards at that level, and the level's winner is the (score, global ordinal) minimum over the shards
+ * (mpc_amd/distributed.py: combine_tree_levels).  h_result is this shard's own best path.  split_level must be below
+ * max_levels and that level must have at least n_shards nodes.  No counterpart in the reference (one device: none). */
+int         mpc_hip_solve_tree_shard(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels,
+                                     int precision, mpc_time_fn now, void *now_ctx, double end_time,
+                                     uint64_t max_nodes, int split_level, uint32_t shard, uint32_t n_shards,
+                                     mpc_tree_level *h_level_best, mpc_result *h_result);
+
 /* ---- single rollout (VehicleState::simulate itself, VehicleState.h:43-55) --------------------------------
  * Runs ONE control sequence (host arrays [depth]) through the strict kernel and returns the state after every
  * level.  Used by the host wrapper for getStateAfterCurrentControl-style calls and by the parity tests. */

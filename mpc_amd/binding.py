@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_substep_schedule", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
     "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
-    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_combine_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_rollout",
+    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_combine_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
 )
 
 
@@ -127,6 +127,8 @@ def load_library(path=None):
     L.mpc_hip_set_timing.argtypes = [vp, C.c_uint32]
     L.mpc_hip_timing.argtypes = [vp, i32, C.POINTER(u64), dp, dp]
     L.mpc_hip_solve_tree.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, C.POINTER(TreeLevel), RP]
+    L.mpc_hip_solve_tree_shard.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, i32, C.c_uint32, C.c_uint32,
+                                           C.POINTER(TreeLevel), RP]
     L.mpc_hip_rollout.argtypes = [vp, PP, dp, dp, i32, RP]
     if path is None:
         _lib = L
@@ -299,12 +301,20 @@ class Solver:
         return n.value, k.value, t.value
 
     # ---- tree search / single rollout --------------------------------------------------------------------
-    def solve_tree(self, problem, max_levels, precision=PREC_F64, now=None, end_time=0.0, max_nodes=0):
+    def solve_tree(self, problem, max_levels, precision=PREC_F64, now=None, end_time=0.0, max_nodes=0,
+                   split_level=0, shard=0, n_shards=1):
+        """n_shards > 1: this GPU's share of a search split after `split_level` (mpc_hip_solve_tree_shard); combine
+        the shards' levels with mpc_amd.distributed.combine_tree_levels."""
         r = Result()
         levels = (TreeLevel * max(max_levels, 1))()
         cb = TIME_FN(lambda ctx: float(now())) if now is not None else C.cast(None, TIME_FN)
-        _check(self._L.mpc_hip_solve_tree(self._h, C.byref(problem), max_levels, precision, cb, None,
-                                          float(end_time), max_nodes, levels, C.byref(r)))
+        if n_shards == 1:
+            _check(self._L.mpc_hip_solve_tree(self._h, C.byref(problem), max_levels, precision, cb, None,
+                                              float(end_time), max_nodes, levels, C.byref(r)))
+        else:
+            _check(self._L.mpc_hip_solve_tree_shard(self._h, C.byref(problem), max_levels, precision, cb, None,
+                                                    float(end_time), max_nodes, split_level, shard, n_shards,
+                                                    levels, C.byref(r)))
         return r, levels
 
     def rollout(self, problem, rudders, throttles, precision=PREC_F64):

@@ -57,6 +57,7 @@ struct TreeLevelBuf {
     uint32_t *parent = nullptr, *count = nullptr, *offset = nullptr;   /* offset has cap + 1 entries */
     size_t cap = 0;
     size_t n = 0;
+    size_t first = 0;      /* multi-GPU shard: the level is the slice [first, first + n) of the full level */
 };
 
 /* device-side view of one TreeLevelBuf */

@@ -70,8 +70,9 @@ __device__ inline uint32_t control_count(const DevProblem &P, double last_r, dou
 
 static LevelPtrs ptrs(const TreeLevelBuf &b)
 {
-    return LevelPtrs{b.x, b.y, b.h, b.v, b.rpm, b.cmg, b.sog, b.last_r, b.last_t, b.cum, b.last_score,
-                     b.parent, b.count, b.offset};
+    const size_t f = b.first;       /* a sliced level looks like a whole one to the kernels */
+    return LevelPtrs{b.x + f, b.y + f, b.h + f, b.v + f, b.rpm + f, b.cmg + f, b.sog + f, b.last_r + f, b.last_t + f,
+                     b.cum + f, b.last_score + f, b.parent + f, b.count + f, b.offset + f};
 }
 
 /* Node records.  strict: x y h v rpm cmg sog.  fast (MPC_PREC_FAST): x, y through the water, h = sin(heading),
@@ -595,6 +596,7 @@ static int publish_level(mpc_hip_handle *h, int l)
 
 static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
                            mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
+                           int split_level, uint32_t shard, uint32_t n_shards,
                            mpc_tree_level *h_level_best, mpc_result *h_result)
 {
     const bool fast = precision == MPC_PREC_FAST;
@@ -603,6 +605,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     if (max_nodes > 0xFFFFFFF0ull) max_nodes = 0xFFFFFFF0ull;
     if (int s = mpc_hip_upload_problems(h, h_problem, nullptr, 1)) return s;
     if ((int)h->tree.size() < max_levels + 1) h->tree.resize(max_levels + 1);
+    for (auto &b : h->tree) b.first = 0;
     if (!h->d_level_ptrs) {
         HIP_TRY(hipMalloc(&h->d_level_ptrs, sizeof(LevelPtrs) * (MPC_MAX_DEPTH + 2)));
         h->h_level_ptrs.assign(MPC_MAX_DEPTH + 2, LevelPtrs{});
@@ -633,7 +636,8 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             h->cap_scan_tmp = ((size_t)ntile + 2) * 2;
         }
         hipLaunchKernelGGL(count_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, A.count, n, h->d_scan_tmp);
+        const LevelPtrs PA = ptrs(A);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, PA.count, n, h->d_scan_tmp);
         hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->d_scan_tmp, ntile);
         const size_t nbound = (size_t)n * 30 / 256 + 2;                    /* <= 30 children per node (6 x 5) */
         if (nbound > h->cap_bpar) {
@@ -642,7 +646,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             HIP_TRY(hipMalloc(&h->d_bpar, sizeof(uint32_t) * nbound));
             h->cap_bpar = nbound;
         }
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, A.count, n, h->d_scan_tmp, A.offset, h->d_bpar);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, PA.count, n, h->d_scan_tmp, PA.offset, h->d_bpar);
         HIP_TRY(hipGetLastError());
         uint32_t tot[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_scan_tmp + ntile, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, h->stream));
@@ -654,6 +658,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         /* the last level asked for is never a parent level: expanded without stores (strict: into a one-node buffer
          * that receives the winner's record; fast: the winner comes from its path) */
         const bool stored = it + 1 < max_levels;
+        B.first = 0;
         if (int s = ensure_level(h, B, stored ? nchild : 1)) {
             if (s == MPC_ERR_HIP) { (void)hipGetLastError(); break; }     /* out of memory: stop like a deadline */
             return s;
@@ -701,6 +706,16 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             memcpy(&h_level_best[it].best_score, &h->h_pair[3], sizeof(double));
             memcpy(&h_level_best[it].best_cumulative, &h->h_pair[2], sizeof(double));
         }
+        if (n_shards > 1 && it + 1 == split_level) {
+            /* every shard has expanded this level in full; from here on this one keeps a contiguous slice of its
+             * nodes (DFS order is preserved within and across shards) */
+            if (!stored) { mpc_set_err("solve_tree_shard: split_level must be below max_levels"); return MPC_ERR_INVALID; }
+            if (nchild < n_shards) { mpc_set_err("solve_tree_shard: the split level has fewer nodes than shards"); return MPC_ERR_INVALID; }
+            const uint64_t base = nchild / n_shards, extra = nchild % n_shards;
+            B.first = (size_t)(shard * base + std::min<uint64_t>(shard, extra));
+            B.n = (size_t)(base + (shard < extra ? 1 : 0));
+            if (int s = publish_level(h, it + 1)) return s;
+        }
     }
     HIP_TRY(hipEventRecord(ev[1], h->stream));
     if (overflow) {
@@ -747,12 +762,17 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     return MPC_OK;
 }
 
-extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
-                                  mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
-                                  mpc_tree_level *h_level_best, mpc_result *h_result)
+static int solve_tree_checked(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
+                              mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
+                              int split_level, uint32_t shard, uint32_t n_shards,
+                              mpc_tree_level *h_level_best, mpc_result *h_result)
 {
     if (!h || !h_problem || !h_result) { mpc_set_err("solve_tree: NULL argument"); return MPC_ERR_INVALID; }
     if (precision != MPC_PREC_F64 && precision != MPC_PREC_FAST) { mpc_set_err("unknown precision"); return MPC_ERR_INVALID; }
+    if (n_shards == 0 || shard >= n_shards || (n_shards > 1 && split_level < 1)) {
+        mpc_set_err("solve_tree_shard: shard index / count / split level out of range");
+        return MPC_ERR_INVALID;
+    }
     if (int s = mpc_check_problem(h_problem, precision)) return s;
     if (max_levels > h_problem->depth) { mpc_set_err("solve_tree: max_levels exceeds the checkpoints supplied"); return MPC_ERR_INVALID; }
     if (precision == MPC_PREC_FAST)
@@ -767,8 +787,27 @@ extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_proble
         h_result->status = MPC_ERR_NO_ITERATION;
         return MPC_ERR_NO_ITERATION;
     }
-    int s = solve_tree_once(h, h_problem, max_levels, precision, now, now_ctx, end_time, max_nodes, h_level_best, h_result);
+    int s = solve_tree_once(h, h_problem, max_levels, precision, now, now_ctx, end_time, max_nodes, split_level, shard,
+                            n_shards, h_level_best, h_result);
     if (s == MPC_INTERNAL_RERUN_STRICT)
-        s = solve_tree_once(h, h_problem, max_levels, MPC_PREC_F64, now, now_ctx, end_time, max_nodes, h_level_best, h_result);
+        s = solve_tree_once(h, h_problem, max_levels, MPC_PREC_F64, now, now_ctx, end_time, max_nodes, split_level, shard,
+                            n_shards, h_level_best, h_result);
     return s;
+}
+
+extern "C" int mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
+                                  mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
+                                  mpc_tree_level *h_level_best, mpc_result *h_result)
+{
+    return solve_tree_checked(h, h_problem, max_levels, precision, now, now_ctx, end_time, max_nodes, 0, 0, 1,
+                              h_level_best, h_result);
+}
+
+extern "C" int mpc_hip_solve_tree_shard(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
+                                        mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
+                                        int split_level, uint32_t shard, uint32_t n_shards,
+                                        mpc_tree_level *h_level_best, mpc_result *h_result)
+{
+    return solve_tree_checked(h, h_problem, max_levels, precision, now, now_ctx, end_time, max_nodes, split_level, shard,
+                              n_shards, h_level_best, h_result);
 }

@@ -132,3 +132,57 @@ class ShardCombiner:
             return None
         o = self.results.view(self.B, self.P, 2)[self.last[1]]
         return o[:, 0], o[:, 1]
+
+
+# ---- tree search split over GPUs (mpc_hip_solve_tree_shard) ------------------------------------------------------
+def tree_levels_tensor(levels, n_levels, device="cpu"):
+    """this shard's per-level record [n_levels, 3] int64: leaves, winning score bits, winning LOCAL leaf ordinal"""
+    rows = []
+    for l in range(n_levels):
+        bits = int(np.float64(levels[l].best_score).view(np.int64))
+        rows.append([int(levels[l].n_leaves), bits, int(np.uint64(levels[l].best_leaf).view(np.int64))])
+    return torch.tensor(rows, dtype=torch.int64, device=device)
+
+
+def combine_tree_levels(gathered, split_level):
+    """gathered: int64 [n_shards, n_levels, 3] (tree_levels_tensor of every shard, shard order = slice order).
+    -> list per level of (total leaves, global DFS ordinal of the winner, score bits, owning shard).  Levels up to
+    split_level were expanded in full by every shard (shard 0's record is the level's); below it a shard's ordinals
+    are local to its leaves, and the shards' leaves are consecutive runs of the full level in shard order, so
+    global = local + the lower shards' leaves; the winner is the (score, global ordinal) minimum: the reference's
+    first strict minimum in DFS order (controller.cpp:158-166)."""
+    g = np.asarray(gathered.cpu().numpy() if hasattr(gathered, "cpu") else gathered, dtype=np.int64)
+    n_shards, n_levels, _ = g.shape
+    out = []
+    for l in range(n_levels):
+        if l < split_level:
+            out.append((int(g[0, l, 0]), int(g[0, l, 2]), int(g[0, l, 1]), 0))
+            continue
+        prefix = np.concatenate([[0], np.cumsum(g[:, l, 0])[:-1]])
+        best = None
+        for s in range(n_shards):
+            if g[s, l, 0] == 0:
+                continue
+            cand = (int(g[s, l, 1]), int(prefix[s] + g[s, l, 2]), s)          # non-negative scores order like their bits
+            if best is None or cand[:2] < best[:2]:
+                best = cand
+        out.append((int(g[:, l, 0].sum()), best[1], best[0], best[2]))
+    return out
+
+
+def solve_tree_sharded(solver, problem, max_levels, split_level, precision=1, group=None):
+    """Every rank of `group` runs its shard of the search on its GPU, the per-level records are all-gathered (24 bytes
+    per level and rank) and combined.  -> (combined levels, this rank's Result, owner rank of the final winner)."""
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    res, levels = solver.solve_tree(problem, max_levels, precision, split_level=split_level, shard=rank, n_shards=world)
+    dev = "cuda" if on and dist.get_backend(group) == "nccl" else "cpu"
+    mine = tree_levels_tensor(levels, res.levels, dev)
+    if world > 1:
+        gathered = torch.empty((world,) + tuple(mine.shape), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+    else:
+        gathered = mine.unsqueeze(0)
+    combined = combine_tree_levels(gathered, split_level)
+    return combined, res, combined[-1][3]

@@ -97,3 +97,54 @@ def test_all_gather_combine_matches_the_two_allreduce_form():
     key, cand = res[0]
     assert key[:2] == [1.5, 2.0] and key[2] == float("inf")
     assert cand[0] == 100 + 3 and cand[1] == 4 and cand[2] == np.iinfo(np.int64).max
+
+
+class _FakeLevel:
+    def __init__(self, n_leaves, best_leaf, best_score):
+        self.n_leaves, self.best_leaf, self.best_score = n_leaves, best_leaf, best_score
+
+
+class _FakeResult:
+    def __init__(self, levels):
+        self.levels = levels
+
+
+class _FakeSolver:
+    """stands in for the GPU solver: what rank r's shard of a search would report per level"""
+
+    def __init__(self, table):
+        self.table = table
+
+    def solve_tree(self, problem, max_levels, precision, split_level, shard, n_shards):
+        lv = [_FakeLevel(*self.table[shard][l]) for l in range(max_levels)]
+        return _FakeResult(max_levels), lv
+
+
+def _tree_worker(rank, world, port, table, out):
+    from mpc_amd.distributed import solve_tree_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    combined, res, owner = solve_tree_sharded(_FakeSolver(table), None, 4, split_level=2)
+    out[rank] = (combined, owner)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_tree_levels_combine_over_gloo():
+    world = 3
+    # levels 0, 1: expanded in full by every shard; level 2: the minimum sits on shard 1; level 3: an exact tie between
+    # shards 0 and 2 -> the lower global DFS ordinal (shard 0's) wins
+    table = [
+        [(15, 4, 2.5), (270, 33, 1.5), (1000, 999, 0.75), (18000, 17, 0.125)],
+        [(15, 4, 2.5), (270, 33, 1.5), (1200, 5, 0.5), (20000, 0, 0.25)],
+        [(15, 4, 2.5), (270, 33, 1.5), (900, 0, 0.75), (16000, 3, 0.125)],
+    ]
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_tree_worker, args=(world, _free_port(), table, out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert res[0] == res[1] == res[2]
+    combined, owner = res[0]
+    assert combined[0] == (15, 4, _bits(2.5), 0) and combined[1] == (270, 33, _bits(1.5), 0)
+    assert combined[2] == (3100, 1000 + 5, _bits(0.5), 1)
+    assert combined[3] == (54000, 17, _bits(0.125), 0) and owner == 0

@@ -141,3 +141,28 @@ def test_deadline_and_node_budget(solver):
     # a level wider than max_nodes ends the search the same way
     res, levels = solver.solve_tree(p, depth, max_nodes=1000)
     assert res.levels == 2                                   # level 3 has 3745 leaves
+
+
+@pytest.mark.parametrize("prec", [M.PREC_F64, M.PREC_FAST])
+@pytest.mark.parametrize("n_shards,split", [(2, 1), (3, 2), (8, 2)])
+def test_sharded_search_equals_the_whole_search(solver, prec, n_shards, split):
+    """mpc_hip_solve_tree_shard (tree mode): the shards of one GPU-count run one after the other on this
+    GPU; combined, every level's leaf count, winner (global DFS ordinal) and score are the unsharded search's, and the
+    owning shard returns the same trajectory."""
+    import torch
+    from mpc_amd.distributed import tree_levels_tensor, combine_tree_levels
+    p, depth = _semicircle(6.5)
+    depth = min(depth, 5)
+    whole, wl = solver.solve_tree(p, depth, precision=prec)
+    shards = [solver.solve_tree(p, depth, precision=prec, split_level=split, shard=s, n_shards=n_shards) for s in range(n_shards)]
+    gathered = torch.stack([tree_levels_tensor(lv, depth) for _, lv in shards])
+    combined = combine_tree_levels(gathered, split)
+    for l in range(depth):
+        total, ordinal, bits, owner = combined[l]
+        assert total == wl[l].n_leaves and ordinal == wl[l].best_leaf, (l, combined[l])
+        assert bits == int(np.float64(wl[l].best_score).view(np.int64))
+    owner = combined[-1][3]
+    assert traj_array(shards[owner][0]).tobytes() == traj_array(whole).tobytes()
+    assert sum(r.evaluated for r, _ in shards) >= whole.evaluated           # the levels above the split are redundant
+    with pytest.raises(M.MpcError):
+        solver.solve_tree(p, depth, split_level=depth, shard=0, n_shards=2)  # the split level must be a stored level
