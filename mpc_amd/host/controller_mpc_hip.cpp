@@ -133,7 +133,13 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
     int status;
     {
         Lease lease;
-        status = mpc_hip_solve_tree(lease.h, &problem, maxIterations, MPC_PREC_F64, poll, &ctx, endTime, 0, nullptr, &result);
+        /* MPC_HIP_TREE_PRECISION=fast: expand with the streamlined model; the strict model still decides every level
+         * and the returned states are the strict path's (same leaf, same bits, sooner at depth >= 6) */
+        static const int precision = [] {
+            const char *e = getenv("MPC_HIP_TREE_PRECISION");
+            return (e && std::string(e) == "fast") ? MPC_PREC_FAST : MPC_PREC_F64;
+        }();
+        status = mpc_hip_solve_tree(lease.h, &problem, maxIterations, precision, poll, &ctx, endTime, 0, nullptr, &result);
     }
     if (ctx.cancelled) return {};                                                             /* :83-86 */
     if (status == MPC_ERR_NO_ITERATION || status == MPC_ERR_NON_FINITE) {

@@ -9,9 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "host", "host_tests")
 
 
-def _run(mode, timeout):
+def _run(mode, timeout, env=None):
     assert os.path.exists(EXE), "build it: python __graft_entry__.py (make -C tests/host)"
-    p = subprocess.run([EXE, mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True)
+    p = subprocess.run([EXE, mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True,
+                       env=dict(os.environ, **(env or {})))
     print(p.stdout[-3000:])
     assert p.returncode == 0, p.stdout[-3000:]
     assert "0 failed" in p.stdout
@@ -22,5 +23,7 @@ def test_host_classes_cpu():
 
 
 @pytest.mark.gpu
-def test_controller_mpc_on_gpu():
-    _run("gpu", 110)
+@pytest.mark.parametrize("precision", ["f64", "fast"])
+def test_controller_mpc_on_gpu(precision):
+    """the same assertions (equality with the oracle's tree search included) whichever model expands the tree"""
+    _run("gpu", 110, {"MPC_HIP_TREE_PRECISION": precision})
