@@ -22,6 +22,11 @@ def shard_range(n_total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
+def _global_ordinal(local, offset):
+    """local winning ordinals -> global ones; -1 (UINT64_MAX: nothing selected, no finite score) -> INT64_MAX"""
+    return torch.where(local == -1, torch.full_like(local, I64_MAX), local + offset)
+
+
 def combine_winners(winners, ordinal_offset=0, group=None, always=False):
     """winners: int64 tensor [P, 2] (or [2]) on this rank = (score bits, local winning ordinal) per problem, as
     mpc_hip_copy_winners leaves it.  ordinal_offset: what to add to the local ordinals to make them global (0 if
@@ -32,10 +37,10 @@ def combine_winners(winners, ordinal_offset=0, group=None, always=False):
     key = w[:, 0].clone()
     if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1):
         dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
-        cand = torch.where(w[:, 0] == key, w[:, 1] + ordinal_offset, torch.full_like(key, I64_MAX))
+        cand = torch.where(w[:, 0] == key, _global_ordinal(w[:, 1], ordinal_offset), torch.full_like(key, I64_MAX))
         dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=group)
     else:
-        cand = w[:, 1] + ordinal_offset
+        cand = _global_ordinal(w[:, 1], ordinal_offset)
     return key, cand
 
 
@@ -132,6 +137,52 @@ class ShardCombiner:
             return None
         o = self.results.view(self.B, self.P, 2)[self.last[1]]
         return o[:, 0], o[:, 1]
+
+
+def combine_winners_exact(winners, ordinal_offset, strict_score, group=None, refine_rel=1.0e-6):
+    """The fast mode's cross-shard decision made exact.  Inside a shard, candidates within MPC_REFINE_REL of the
+    shard's minimum are already decided by the strict model; ACROSS shards the packed winners carry fast scores, which
+    are only good to ~1e-7.  Here the winners are all-gathered; wherever the best two shards of a problem lie within
+    refine_rel of each other, each of those shards re-scores ITS winner with the strict model -- strict_score(problem
+    index, local ordinal) -> float, e.g. a one-candidate mpc_hip_eval_* call in MPC_PREC_F64 -- and the strict (score,
+    global ordinal) decides, as the reference's first strict minimum would (controller.cpp:158-166).  Costs one host
+    synchronisation, and two more 8-byte collectives only when such a tie exists.  -> (score bits [P], global
+    ordinal [P]) as int64 tensors on the winners' device, identical on every rank."""
+    w = winners.view(-1, 2)
+    P = w.shape[0]
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not on:
+        return w[:, 0].clone(), _global_ordinal(w[:, 1], ordinal_offset)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = torch.stack([w[:, 0], _global_ordinal(w[:, 1], ordinal_offset)], dim=1).contiguous()
+    gathered = torch.empty((world, P, 2), dtype=torch.int64, device=w.device)
+    dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+    g = gathered.cpu().numpy()
+    keys = g[:, :, 0].view(np.float64)                              # non-negative scores
+    kmin = keys.min(axis=0)
+    near = keys <= kmin * (1.0 + refine_rel)                        # [world, P]; +inf rows stay out unless all are
+    near &= np.isfinite(keys)
+    tied = np.flatnonzero(near.sum(axis=0) > 1)
+    strict = torch.full((P,), I64_MAX, dtype=torch.int64, device=w.device)
+    if tied.size:                                                   # the same decision on every rank
+        vals = np.full(P, np.inf)
+        for p in tied:
+            if near[rank, p]:
+                vals[p] = float(strict_score(int(p), int(w[p, 1].item())))
+        strict = torch.from_numpy(np.where(np.isfinite(vals), vals, np.inf).view(np.int64).copy()).to(w.device)
+        skey = strict.clone()
+        dist.all_reduce(skey, op=dist.ReduceOp.MIN, group=group)
+        cand = torch.where(strict == skey, mine[:, 1], torch.full_like(skey, I64_MAX))
+        dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=group)
+        skey, cand = skey.cpu().numpy(), cand.cpu().numpy()
+    out_k = np.empty(P, dtype=np.int64); out_o = np.empty(P, dtype=np.int64)
+    for p in range(P):
+        if tied.size and p in tied:
+            out_k[p], out_o[p] = skey[p], cand[p]
+        else:
+            col = [(int(g[s, p, 0]), int(g[s, p, 1])) for s in range(world)]
+            out_k[p], out_o[p] = min(col)
+    return torch.from_numpy(out_k).to(w.device), torch.from_numpy(out_o).to(w.device)
 
 
 # ---- tree search split over GPUs (mpc_hip_solve_tree_shard) ------------------------------------------------------

@@ -148,3 +148,37 @@ def test_sharded_tree_levels_combine_over_gloo():
     assert combined[0] == (15, 4, _bits(2.5), 0) and combined[1] == (270, 33, _bits(1.5), 0)
     assert combined[2] == (3100, 1000 + 5, _bits(0.5), 1)
     assert combined[3] == (54000, 17, _bits(0.125), 0) and owner == 0
+
+
+def _exact_worker(rank, world, port, out):
+    from mpc_amd.distributed import combine_winners_exact
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # problem 0: the shards' fast scores differ by 3e-8 relative (inside the fast model's error), and the strict model
+    # ranks them the other way round; problem 1: clearly apart; problem 2: no finite score anywhere
+    fast = [[2.00000000, 5.0, float("inf")], [2.00000006, 4.0, float("inf")]][rank]
+    strict = {0: [2.0000000300, 2.0000000299][rank]}
+    local = [[3, 8, -1], [5, 2, -1]][rank]
+    calls = []
+
+    def strict_score(p, ordinal):
+        calls.append((p, ordinal))
+        return strict[p]
+    w = torch.tensor([[_bits(fast[p]), local[p]] for p in range(3)], dtype=torch.int64)
+    key, cand = combine_winners_exact(w, ordinal_offset=rank * 100, strict_score=strict_score)
+    out[rank] = (bits_to_score(key).tolist(), cand.tolist(), calls)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cross_shard_near_ties_are_decided_by_the_strict_model():
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_exact_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+        res = [out[r] for r in range(2)]
+    assert res[0][:2] == res[1][:2]
+    key, cand, _ = res[0]
+    assert key[0] == 2.0000000299 and cand[0] == 100 + 5          # rank 1's winner, although its fast score was higher
+    assert key[1] == 4.0 and cand[1] == 100 + 2
+    assert key[2] == float("inf") and cand[2] == np.iinfo(np.int64).max
+    assert res[0][2] == [(0, 3)] and res[1][2] == [(0, 5)]         # only the tied problem was re-scored, once per shard
