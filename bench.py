@@ -182,6 +182,8 @@ def main():
                                  always=args.force_collective) if combine else None
 
         def step():
+            if combiner:
+                combiner.begin()
             launch()
             if combiner:
                 combiner.submit()

@@ -197,6 +197,11 @@ int         mpc_hip_device_winners(mpc_hip_handle *h, uint64_t **d_winners);
 /* copy the packed winners (2 uint64 per problem) to caller-owned device memory, on the handle's stream: the
  * form a host that owns its communicator buffers (torch.distributed / RCCL) uses for the min-allreduce */
 int         mpc_hip_copy_winners(mpc_hip_handle *h, uint64_t *d_dst);
+/* The copy without the copy: from the next run on, the finish kernel ALSO writes the packed winners (2 uint64 per
+ * problem) to d_dst -- caller-owned device memory that must stay valid until those runs have completed; NULL turns
+ * it off.  A stream of solves that batches its winners for one collective (ShardCombiner) points this at the next row
+ * of its batch buffer before every run instead of enqueuing a 16-byte device copy after it (~3 us per solve). */
+int         mpc_hip_set_winner_sink(mpc_hip_handle *h, uint64_t *d_dst);
 /* Combine the winners of `n_shards` shards after ONE all-gather of the copy_winners records:
  * d_gathered[shard][problem][2] -> d_out[problem][2] = (smallest score bits, lowest GLOBAL ordinal among the shards
  * that hold it), global ordinal = gathered ordinal + shard * ordinal_stride (0 if the shards were run with their

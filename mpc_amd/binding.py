@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_substep_schedule", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
     "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
-    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_combine_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
+    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
 )
 
 
@@ -124,6 +124,7 @@ def load_library(path=None):
     L.mpc_hip_combine_shards.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp]
     L.mpc_hip_upload_problems_from_plans.argtypes = [vp, PP, C.POINTER(u64), C.POINTER(Plan), dp, C.c_uint32]
     L.mpc_hip_fetch_checkpoints.argtypes = [vp, C.c_uint32, C.POINTER(Checkpoint)]
+    L.mpc_hip_set_winner_sink.argtypes = [vp, vp]
     L.mpc_hip_set_timing.argtypes = [vp, C.c_uint32]
     L.mpc_hip_timing.argtypes = [vp, i32, C.POINTER(u64), dp, dp]
     L.mpc_hip_solve_tree.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, C.POINTER(TreeLevel), RP]
@@ -289,6 +290,10 @@ class Solver:
 
     def combine_shards(self, d_gathered, n_shards, n_problems, ordinal_stride, d_out):
         _check(self._L.mpc_hip_combine_shards(self._h, _ptr(d_gathered), n_shards, n_problems, ordinal_stride, _ptr(d_out)))
+
+    def set_winner_sink(self, d_dst):
+        """runs also write their packed winners to d_dst (a device tensor / pointer; None: off)"""
+        _check(self._L.mpc_hip_set_winner_sink(self._h, _ptr(d_dst)))
 
     def set_timing(self, period):
         """HIP events on every `period`-th run (1 = all, 0 = none)."""

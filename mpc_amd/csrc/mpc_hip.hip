@@ -304,7 +304,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
 #define LAUNCH_K2(SEEDED)                                                                                     \
     hipExtLaunchKernelGGL((finish_kernel<SEEDED>), dim3(h->n_probs), dim3(256), 0, h->stream, k2a, k2b, 0, h->d_probs, d_rud, d_thr, \
                        first, count, selection, fast, (int)uniform, rel, nblk, cpb, h->d_pkey, h->d_pord, h->d_pcnt, h->d_keys, \
-                       d_snap, snap_depth, h->d_winners, h->d_results)
+                       d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->d_results)
     if (seeded) LAUNCH_K2(true); else LAUNCH_K2(false);
 #undef LAUNCH_K2
     HIP_TRY(hipGetLastError());
@@ -418,6 +418,13 @@ extern "C" int mpc_hip_device_winners(mpc_hip_handle *h, uint64_t **d_winners)
 {
     if (!h || !d_winners) { mpc_set_err("device_winners: NULL argument"); return MPC_ERR_INVALID; }
     *d_winners = h->d_winners;
+    return MPC_OK;
+}
+
+extern "C" int mpc_hip_set_winner_sink(mpc_hip_handle *h, uint64_t *d_dst)
+{
+    if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
+    h->d_winner_sink = d_dst;
     return MPC_OK;
 }
 

@@ -82,6 +82,7 @@ struct mpc_hip_handle {
     uint32_t cap_probs = 0, n_probs = 0;
     DevResult *d_results = nullptr, *h_results = nullptr;       /* h_results pinned */
     uint64_t *d_winners = nullptr;
+    uint64_t *d_winner_sink = nullptr;                          /* caller memory that runs also write the winners to */
     uint32_t *d_list_count = nullptr;                           /* per-problem scratch word (tree trace cursor) */
     uint64_t *d_pkey = nullptr, *d_pord = nullptr;              /* K1 workgroup triples */
     uint32_t *d_pcnt = nullptr;

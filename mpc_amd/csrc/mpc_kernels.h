@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
                                                      const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
                                                      const uint32_t *__restrict__ pcnt, const double *__restrict__ keys,
                                                      double *__restrict__ snap_base, int snap_depth,
-                                                     uint64_t *__restrict__ winners, DevResult *__restrict__ results)
+                                                     uint64_t *__restrict__ winners, uint64_t *__restrict__ sink,
+                                                     DevResult *__restrict__ results)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t s_list[LIST_CAP];
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
         if (threadIdx.x == 0) {
             R.key_bits = KEY_INF; R.ordinal = win; R.best_last = 0; R.best_cum = 0; R.refined = 0; R.overflow = overflow;
             winners[2 * p] = KEY_INF; winners[2 * p + 1] = win;
+            if (sink) { sink[2 * p] = KEY_INF; sink[2 * p + 1] = win; }
         }
         return;
     }
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
             R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
             R.refined = 0; R.overflow = overflow;
             winners[2 * p] = kb; winners[2 * p + 1] = win;
+            if (sink) { sink[2 * p] = kb; sink[2 * p + 1] = win; }
         }
     } else if (threadIdx.x == 0) {
         double last = 0, cum = 0;
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
         R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
         R.refined = n > 1 ? n : 0; R.overflow = overflow;
         winners[2 * p] = kb; winners[2 * p + 1] = win;
+        if (sink) { sink[2 * p] = kb; sink[2 * p + 1] = win; }
     }
 }
 

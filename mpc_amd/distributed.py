@@ -73,10 +73,11 @@ def combine_gathered(gathered, n_shards, n_problems, ordinal_stride=0):
 class ShardCombiner:
     """The combine step for throughput runs of independent solves (bench.py --gpus N), batched and pipelined:
 
-        solver.run_*(...) ; combiner.submit()        # per solve
+        combiner.begin() ; solver.run_*(...) ; combiner.submit()        # per solve
         key_bits, ordinal = combiner.flush()         # after the last one: every submitted solve is combined
 
-    submit() copies this rank's winners into the next row of a batch buffer; every `batch` solves ONE asynchronous
+    begin() points the solver's winner sink (mpc_hip_set_winner_sink) at the next row of a batch buffer, so the finish
+    kernel itself deposits this rank's winners there (no device copy per solve); every `batch` solves ONE asynchronous
     all-gather moves batch x 16 bytes per problem and rank (instead of two dependent 8-byte all-reduces per solve:
     fewer, larger collectives), and the gathered batch is reduced by mpc_hip_combine_shards (one tiny kernel) only
     after the NEXT batch's kernels have been enqueued, so the collective's latency hides behind rollouts.
@@ -114,12 +115,23 @@ class ShardCombiner:
         self.last = (r, self.fill - 1)
         self.slot, self.fill = (r + 1) % len(self.win), 0
 
-    def submit(self):
+    def _row(self):
         if self.fill == 0:
             while self.slot in self.pending:          # about to overwrite a batch that is not reduced yet
                 self._reduce(self.pending.pop(0))
         row = 2 * self.P
-        self.solver.copy_winners(self.win[self.slot][self.fill * row:(self.fill + 1) * row])
+        return self.win[self.slot][self.fill * row:(self.fill + 1) * row]
+
+    def begin(self):
+        """before the run whose winners go into the next row"""
+        self.solver.set_winner_sink(self._row())
+        self._begun = True
+
+    def submit(self):
+        """after the run"""
+        if not getattr(self, "_begun", False):        # begin() was skipped: a device copy of the winners instead
+            self.solver.copy_winners(self._row())
+        self._begun = False
         self.fill += 1
         if self.fill == self.B:
             older = list(self.pending)
@@ -129,6 +141,7 @@ class ShardCombiner:
                 self.pending.remove(r)
 
     def flush(self):
+        self.solver.set_winner_sink(None)
         if self.fill:
             self._close_batch()
         while self.pending:

@@ -226,16 +226,24 @@ def test_shard_combiner_single_rank(solver):
     solve is that solve's own winner; partial batches and ring wrap-around included."""
     from mpc_amd.distributed import ShardCombiner, bits_to_score
     p = W.config2_problem(depth=5)
-    comb = ShardCombiner(solver, 1, ordinal_stride=0, batch=3, slots=2)
-    want = None
-    for k in range(8):                       # 2 full batches + a partial one
-        solver.upload([p], [100 + k])
-        solver.run_seeded(0, 2048, M.PREC_FAST)
-        comb.submit()
-        want = solver.fetch()[0]
-    key, ordinal = comb.flush()
-    assert int(ordinal[0].item()) == want.best_ordinal
-    assert bits_to_score(key)[0] == want.best_last
+    for use_sink in (True, False):           # winners deposited by the finish kernel itself / copied afterwards
+        comb = ShardCombiner(solver, 1, ordinal_stride=0, batch=3, slots=2)
+        want, seen = None, []
+        for k in range(8):                   # 2 full batches + a partial one
+            solver.upload([p], [100 + k])
+            if use_sink:
+                comb.begin()
+            solver.run_seeded(0, 2048, M.PREC_FAST)
+            comb.submit()
+            want = solver.fetch()[0]
+            seen.append(want.best_ordinal)
+        key, ordinal = comb.flush()
+        assert int(ordinal[0].item()) == want.best_ordinal
+        assert bits_to_score(key)[0] == want.best_last
+        assert len(set(seen)) > 1            # different seeds, different winners: rows are not mixed up
+        # the last batch holds solves 6 and 7
+        last_batch = comb.results.view(comb.B, 1, 2)[:2, 0, 1].cpu().tolist()
+        assert last_batch == seen[6:8]
 
 
 def test_timing_period_samples_runs_and_changes_no_result(solver):
