@@ -32,19 +32,20 @@ if bench_line:
     tail = ["", "# bench.py JSON line of the same (profiled) run: rollout_kernel_ms=%.5f value=%.4e steps/s roofline.frac=%.4f"
             % (bench_line["rollout_kernel_ms"], bench_line["value"], bench_line["roofline"]["frac"])]
 txt, rows = stats_table(os.path.join(src, "stats", "r1_kernel_stats.csv"),
-                        "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20"
-                        "   (MI355X, fast precision, config 2)", tail)
+                        "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py"
+                        "   (MI355X, fast precision, config 2, default steps/warmup)", tail)
 open(os.path.join(out, tag + "_bench_kernel_stats.txt"), "w").write(txt)
 with open(os.path.join(out, tag + "_bench_kernel_stats.csv"), "w") as f:
     f.write(open(os.path.join(src, "stats", "r1_kernel_stats.csv")).read())
 
-tree = os.path.join(src, "tree", "t_kernel_stats.csv")
-if os.path.exists(tree):
-    extra = ["", "# tools/gpu_probe_tree.py output of the same run:"]
-    extra += ["# " + ln.rstrip() for ln in open(os.path.join(src, "tree.log")) if ln.startswith("depth=")]
-    txt, _ = stats_table(tree, "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/gpu_probe_tree.py"
-                               "   (tree search, depths 3..7, strict precision)", extra)
-    open(os.path.join(out, tag + "_tree_kernel_stats.txt"), "w").write(txt)
+for sub, arg, what in (("tree", "", "strict precision"), ("treefast", " fast", "fast expansion, strict decision")):
+    tree = os.path.join(src, sub, "t_kernel_stats.csv")
+    if os.path.exists(tree):
+        extra = ["", "# tools/gpu_probe_tree.py output of the same run:"]
+        extra += ["# " + ln.rstrip() for ln in open(os.path.join(src, sub + ".log")) if "depth=" in ln]
+        txt, _ = stats_table(tree, "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/gpu_probe_tree.py" + arg +
+                             "   (tree search, depths 3..7, " + what + ")", extra)
+        open(os.path.join(out, tag + "_" + sub + "_kernel_stats.txt"), "w").write(txt)
 
 acc = defaultdict(lambda: [0.0, 0])
 for path in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
@@ -52,7 +53,7 @@ for path in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
         k = (r["Kernel_Name"].split("(")[0][:48], r["Counter_Name"])
         acc[k][0] += float(r["Counter_Value"])
         acc[k][1] += 1
-lines = ["# rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline",
+lines = ["# rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 20 --warmup 5 --ramp-seconds 0 --no-cpu-baseline",
          "# four separate passes (FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM_GUI_ACTIVE TCC_*), MI355X, mean per launch",
          "# FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM): double it",
          "# SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles"]
