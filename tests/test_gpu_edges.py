@@ -1,5 +1,5 @@
 """GPU parity at the edges of the C-ABI's domain: maximum depth and substep count, deep explicit control arrays
-(two staging chunks), sets of one candidate, candidates without a finite score."""
+(two staging chunks), sets of one candidate, candidates without a finite score, sets in which everything ties."""
 import math
 
 import numpy as np
@@ -123,3 +123,22 @@ def test_sizes_beyond_the_maxima_are_refused(solver):
     with pytest.raises(M.MpcError) as e:
         solver.eval_seeded(p, W.SEED, 0, 64, M.PREC_F64)
     assert e.value.status == 8
+
+
+def test_everything_ties(solver):
+    """all weights zero: every candidate scores exactly 0, far more than the 1024 near-ties the fast path lists -- the
+    decision falls back to the strict kernel / strict expansion, and the reference's first-strict-minimum rule picks
+    the FIRST candidate (controller.cpp:158-166)."""
+    p = W.config2_problem(depth=4)
+    p.w_distance = p.w_heading = p.w_speed = 0.0
+    for prec in (M.PREC_FAST, M.PREC_F64):
+        res = solver.eval_seeded(p, W.SEED, 7, 5000, prec)
+        assert res.best_ordinal == 7 and res.best_last == 0.0
+    # the tree: level l's winner is leaf 0 at every level, whichever model expands it
+    q, _plan = W.config1_problem(depth=4)
+    q.w_distance = q.w_heading = q.w_speed = 0.0
+    for prec in (M.PREC_FAST, M.PREC_F64):
+        res, levels = solver.solve_tree(q, 4, precision=prec)
+        assert res.levels == 4 and res.best_ordinal == 0
+        assert [levels[l].best_leaf for l in range(4)] == [0, 0, 0, 0]
+        assert (res.first_rudder, res.first_throttle) == (q.min_rudder, q.min_throttle)     # first child: (minR, minT)
