@@ -178,22 +178,21 @@ __device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle)
     return FastLevelCoef{throttle * MAX_RPM, PROP_COEFFICIENT * cos_ra, (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra};
 }
 
-/* One Euler substep, 28 FP64 instructions (VehicleState.h:111-148 restated for throughput):
- *   rpm slew   rpm += clamp((target - rpm)/dt, +-1000) * dt  ==  clamp(target, rpm - 1000 dt, rpm + 1000 dt)
- *   sqrt       rsq estimate + one coupled Newton (Goldschmidt) step; the +1e-300 keeps rsq finite at rpm == 0
+/* One Euler substep, 26 FP64 instructions (VehicleState.h:111-148 restated for throughput):
+ *   rpm slew   rpm += clamp((target - rpm)/dt, +-1000) * dt, carried as the distance to the target (FastSlew below)
+ *   sqrt       rsq estimate + one coupled Newton (Goldschmidt) step
  *   speed      v += dt/m * (kpc (ps^2 - v^2) - D v^3)  as  v - v^2 (kpcm + dm v) + (kpcm ps) ps   (kpcm, dm carry dt/m)
  *   heading    rotation of (sin h, cos h) by a = yaw_rate*dt, |a| <= 0.05 rad for dt <= 0.1 s: sin to a^5 (2.6e-9 a
  *              relative), cos - 1 to a^4 (2e-11 absolute), written as corrections to the old vector (no cancellation)
  *   position   x += step * sin h', y += step * cos h': step = v*dt, or v alone when the caller carries x/dt, y/dt
  *              through a level of equal substeps (SCALED) */
 template <bool SCALED>
-__device__ inline void fast_substep(double &rpm, double &v, double &sh, double &ch, double &x, double &y,
-                                    double target_rpm, double max_step, double kpcm, double dm, double kyaw_dt,
+__device__ inline void fast_substep(double &m, double &v, double &sh, double &ch, double &x, double &y,
+                                    double sc, double pst, double max_step, double kpcm, double dm, double kyaw_dt,
                                     double dt)
 {
-    constexpr double C_PROP = PROP_RATIO / PROP_PITCH;
-    rpm = fmin(fmax(target_rpm, rpm - max_step), rpm + max_step);
-    const double ps = fma(C_PROP, rpm, 1.0e-300);
+    m = fmax(m - max_step, 0.0);
+    const double ps = fma(sc, m, pst);
     const double y0 = __builtin_amdgcn_rsq(ps);
     const double g = ps * y0;
     const double hh = 0.5 * y0;
@@ -215,11 +214,31 @@ __device__ inline void fast_substep(double &rpm, double &v, double &sh, double &
     y = fma(step, nch, y);
 }
 
+/* The rpm slew of a level in the substeps' own terms: the rpm moves toward its target by 1000 dt per substep until it
+ * is there, so what the substeps carry is m = |rpm - target| (m' = max(m - 1000 dt, 0): two instructions instead of
+ * the four of a clamp) and prop_speed = C rpm = pst + sc m with sc = +-C.  pst = C target is biased by 2^-50 relative
+ * and +1e-300 so that the rounded difference stays positive when the rpm starts at 0 (the reciprocal square root
+ * must not see 0 or a negative rounding residue); 1e-15 relative on prop_speed is far below the model's needs. */
+struct FastSlew { double m, sc, pst, sgn; };
+
+__device__ inline FastSlew fast_slew_begin(double rpm, double target_rpm)
+{
+    constexpr double C_PROP = PROP_RATIO / PROP_PITCH;
+    const double e = rpm - target_rpm;
+    FastSlew z;
+    z.m = fabs(e);
+    z.sgn = copysign(1.0, e);
+    z.sc = copysign(C_PROP, e);
+    z.pst = fma(C_PROP * target_rpm, 1.0 + 0x1p-50, 1.0e-300);
+    return z;
+}
+
 /* STRIDE 0: every substep of the level uses schedule row 0 (held in registers by the caller) */
 template <int STRIDE = SUB_STRIDE>
 __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
 {
     const FastLevelCoef c = fast_level_coef(rudder, throttle);
+    FastSlew z = fast_slew_begin(s.rpm, c.target_rpm);
     if (STRIDE == 0) {
         const double dt = sub[0], max_step = sub[1], dtm = sub[2], inv_dt = sub[5];
         const double kpcm = c.kpc * dtm, dm = DRAG_COEFFICIENT * dtm, kyaw_dt = c.kyaw * dt;
@@ -228,7 +247,7 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
 #pragma unroll MPC_SUBSTEP_UNROLL
 #endif
         for (int k = 0; k < n_sub; k++)
-            fast_substep<true>(s.rpm, s.v, s.sh, s.ch, xs, ys, c.target_rpm, max_step, kpcm, dm, kyaw_dt, dt);
+            fast_substep<true>(z.m, s.v, s.sh, s.ch, xs, ys, z.sc, z.pst, max_step, kpcm, dm, kyaw_dt, dt);
         s.x = xs * dt; s.y = ys * dt;
         s.delta = s.v * dt;
     } else {
@@ -239,11 +258,12 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
         for (int k = 0; k < n_sub; k++) {
             const double *q = sub + k * STRIDE;
             dt = q[0];
-            fast_substep<false>(s.rpm, s.v, s.sh, s.ch, s.x, s.y, c.target_rpm, q[1], c.kpc * q[2],
+            fast_substep<false>(z.m, s.v, s.sh, s.ch, s.x, s.y, z.sc, z.pst, q[1], c.kpc * q[2],
                                 DRAG_COEFFICIENT * q[2], c.kyaw * dt, dt);
         }
         if (n_sub > 0) s.delta = s.v * dt;
     }
+    s.rpm = fma(z.sgn, z.m, c.target_rpm);
 }
 
 /* tracking cost from the fast state; q_last = the schedule row of the level's last substep */
