@@ -178,7 +178,7 @@ __device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle)
     return FastLevelCoef{throttle * MAX_RPM, PROP_COEFFICIENT * cos_ra, (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra};
 }
 
-/* One Euler substep, 26 FP64 instructions (VehicleState.h:111-148 restated for throughput):
+/* One Euler substep, 27 FP64 instructions (VehicleState.h:111-148 restated for throughput):
  *   rpm slew   rpm += clamp((target - rpm)/dt, +-1000) * dt, carried as the distance to the target (FastSlew below)
  *   sqrt       rsq estimate + one coupled Newton (Goldschmidt) step
  *   speed      v += dt/m * (kpc (ps^2 - v^2) - D v^3)  as  v - v^2 (kpcm + dm v) + (kpcm ps) ps   (kpcm, dm carry dt/m)

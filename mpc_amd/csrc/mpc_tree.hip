@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void leaf_record_kernel(const DevProblem *__res
 
 /* ---- fast-model expansion (MPC_PREC_FAST) -------------------------------------------------------------------
  * The same tree (the control sets depend on controls only, never on states), expanded with the streamlined model
- * of mpc_model.h (28 instead of ~150 FP64 instructions per substep).  What makes the result the reference's:
+ * of mpc_model.h (27 instead of ~150 FP64 instructions per substep).  What makes the result the reference's:
  * every leaf whose fast last-step score is within MPC_REFINE_REL of the level's minimum is re-evaluated along its
  * whole path from the root with the strict model, the strict (score, ordinal) decides, and the returned trajectory
  * and scores are the strict path's -- bit for bit what the strict expansion returns for the same leaf. */
