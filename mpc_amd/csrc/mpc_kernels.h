@@ -24,7 +24,7 @@ struct ControlSource {
     uint64_t n;                  /* stride of the explicit arrays */
     uint64_t seed;               /* seeded */
     double last_r, last_t;
-    const float *staged;         /* explicit controls of THIS lane staged in LDS by stage_controls(), or nullptr */
+    const float *staged;         /* explicit controls of THIS lane staged in LDS by ctl_chunk_store(), or nullptr */
     uint32_t staged_stride;      /* = blockDim.x */
 };
 
@@ -34,25 +34,28 @@ struct ControlSource {
  * than branch (same address, same LDS word).  depth is a KERNEL ARGUMENT here, not P.depth, so the loads do not
  * wait for a scalar load of the problem record. */
 #define CTL_CHUNK 32
-__device__ inline void stage_controls(const float *__restrict__ rud, const float *__restrict__ thr, uint64_t n,
-                                      uint64_t index, bool live, int depth, float *ctl)
+/* One chunk in two halves, so that K1 can put the problem record's loads between them: all of it is one basic block
+ * (clamped indices instead of branches; lanes beyond the set load the last candidate's controls into their own LDS
+ * words), which is what lets every load be issued before the first wait. */
+__device__ inline void ctl_chunk_load(const float *__restrict__ rud, const float *__restrict__ thr, uint64_t n,
+                                      uint64_t index, int depth, int base, float (&a)[CTL_CHUNK], float (&b)[CTL_CHUNK])
 {
-    if (live) {
-        for (int base = 0; base < depth; base += CTL_CHUNK) {
-            float a[CTL_CHUNK], b[CTL_CHUNK];
 #pragma unroll
-            for (int j = 0; j < CTL_CHUNK; j++) {
-                const int l = min(base + j, depth - 1);
-                a[j] = rud[(uint64_t)l * n + index];
-                b[j] = thr[(uint64_t)l * n + index];
-            }
+    for (int j = 0; j < CTL_CHUNK; j++) {
+        const int l = min(base + j, depth - 1);
+        a[j] = rud[(uint64_t)l * n + index];
+        b[j] = thr[(uint64_t)l * n + index];
+    }
+}
+
+__device__ inline void ctl_chunk_store(float *ctl, int depth, int base, const float (&a)[CTL_CHUNK],
+                                       const float (&b)[CTL_CHUNK])
+{
 #pragma unroll
-            for (int j = 0; j < CTL_CHUNK; j++) {
-                const int l = min(base + j, depth - 1);
-                ctl[(2 * l) * blockDim.x + threadIdx.x] = a[j];
-                ctl[(2 * l + 1) * blockDim.x + threadIdx.x] = b[j];
-            }
-        }
+    for (int j = 0; j < CTL_CHUNK; j++) {
+        const int l = min(base + j, depth - 1);
+        ctl[(2 * l) * blockDim.x + threadIdx.x] = a[j];
+        ctl[(2 * l + 1) * blockDim.x + threadIdx.x] = b[j];
     }
     /* each lane reads back only what it wrote: no barrier needed */
 }
@@ -192,12 +195,19 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
     const double row0[6] = {subL[0], subL[1], subL[2], subL[3], subL[4], subL[5]};
     last = 0.0; cum = 0.0;
     if (traj) traj[0] = mpc_level_state{s.x, s.y, P.sh, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
+    /* A lone wave per SIMD has nothing to hide a latency behind, so what a level reads from LDS is requested one
+     * substep loop ahead: level l+1's controls and level l's checkpoint are in flight while level l integrates. */
+    double r_next = 0, t_next = 0;
+    if (P.depth > 0) fetch_control<SEEDED, STAGED>(c, ordinal, index, 0, r_next, t_next);
     for (int l = 0; l < P.depth; l++) {
-        double r, t;
-        fetch_control<SEEDED, STAGED>(c, ordinal, index, l, r, t);
+        const double r = r_next, t = t_next;
+        fetch_control<SEEDED, STAGED>(c, ordinal, index, min(l + 1, P.depth - 1), r_next, t_next);
+        const double *cpv = cpL + l * CP_STRIDE;
+        double cp[CP_STRIDE];
+        cp[3] = cpv[3]; cp[4] = cpv[4]; cp[5] = cpv[5]; cp[6] = cpv[6]; cp[7] = cpv[7];
         if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub);
         else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub);
-        last = fast_score(cpL + l * CP_STRIDE, s, w, q_last);
+        last = fast_score(cp, s, w, q_last);
         cum += last;
         if (traj)
             traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta,
@@ -231,9 +241,22 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
     /* prologue: every global load of the workgroup is issued before the first wait (problem record, then controls;
      * explicit sets hold one problem, whose depth is snap_depth) */
     StagedProblem staged;
+    float ca[CTL_CHUNK], cb[CTL_CHUNK];
+    const uint64_t ic = i < count ? i : count - 1;          /* count >= 1 (host) */
     stage_problem_load(P, staged);
-    if (!SEEDED) stage_controls(rud, thr, count, i, i < count, snap_depth, ctlL);
+    if (!SEEDED) ctl_chunk_load(rud, thr, count, ic, snap_depth, 0, ca, cb);            /* snap_depth >= 1 (host) */
+    /* all global loads first, then the LDS writes (left alone, the scheduler interleaves them and the first wait
+     * comes with half of the loads still to be issued): 0x020 = VMEM reads, 0x200 = DS writes */
+    __builtin_amdgcn_sched_group_barrier(0x020, STAGE_TRIPS + 2 * CTL_CHUNK, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, STAGE_TRIPS + 2 * CTL_CHUNK, 0);
     stage_problem_store(staged, cpL);
+    if (!SEEDED) {
+        ctl_chunk_store(ctlL, snap_depth, 0, ca, cb);
+        for (int base = CTL_CHUNK; base < snap_depth; base += CTL_CHUNK) {       /* deeper than one chunk: a round trip each */
+            ctl_chunk_load(rud, thr, count, ic, snap_depth, base, ca, cb);
+            ctl_chunk_store(ctlL, snap_depth, base, ca, cb);
+        }
+    }
     uint64_t k = ~0ull, o = ~0ull;
     double mykey = __longlong_as_double((long long)KEY_INF);
     if (i < count) {
