@@ -266,7 +266,9 @@ def main():
                        "throttle": res.first_throttle, "last_score": res.best_last,
                        "global_ordinal_after_combine": (int(combined[1][0].item()) if combined else None)},
             "roofline": {
-                "bound": "valu (FP64 vector; not mfma, not hbm -- sequential per-candidate ODE integration)",
+                "bound": "valu",
+                "bound_note": "FP64 vector ALU (SURVEY.md 8d): neither mfma nor hbm -- sequential per-candidate ODE "
+                              "integration, no dense contraction; HBM figures under 'hbm'",
                 "kernel": "rollout_kernel", "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flop / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": measured_traffic() if args.workload == "config2" and prec == M.PREC_FAST else None,
