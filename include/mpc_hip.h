@@ -186,6 +186,23 @@ int         mpc_hip_upload_problems_from_plans(mpc_hip_handle *h, const mpc_prob
                                                uint32_t n_problems);
 /* the checkpoints of one resident problem as the kernels see them (h_out[depth]); for display and tests */
 int         mpc_hip_fetch_checkpoints(mpc_hip_handle *h, uint32_t problem, mpc_checkpoint *h_out);
+/* Batched CurrentEstimator::getCurrent (reference CurrentEstimator.cpp:15-41; its caller mpc_node.cpp:190-192 runs it
+ * before every solve): vessel p's history is h_samples[p * stride .. + h_counts[p]), oldest first, each sample the
+ * State at an updateEstimate call and the controls in effect (CurrentEstimator.cpp:11); h_actual[3p..] = x, y, time of
+ * the state the estimate is asked for.  The replay runs on the device, a lane per vessel, in the strict FP64 model
+ * with no current, and (actual - reckoned) / (query time - oldest sample time) is the estimate; (0, 0) for fewer
+ * than MPC_CURRENT_MIN_SAMPLES samples or a query not after the oldest sample, as the reference returns.  (The
+ * reference's 20-update skip and 600-sample cap are updateEstimate's, i.e. the caller's history keeping.)
+ * h_currents_out (optional): [n][2] = cx, cy.  apply != 0: n must equal the resident problems and estimate p becomes
+ * problem p's current for the following runs (what controller.cpp:398-400 stores per solve), rewritten in the
+ * resident records on the device.  Synchronises the stream. */
+#define MPC_CURRENT_MIN_SAMPLES 10        /* CurrentEstimator.cpp:18 */
+#define MPC_CURRENT_MAX_SAMPLES 600       /* CurrentEstimator.h:82 c_BufferSize */
+#define MPC_CURRENT_MAX_SPAN 3600.0       /* seconds of replay per vessel this library accepts (the reference keeps 60 s) */
+typedef struct { double x, y, heading, speed, time, rudder, throttle; } mpc_history_sample;
+int         mpc_hip_estimate_currents(mpc_hip_handle *h, const mpc_history_sample *h_samples, const uint32_t *h_counts,
+                                      uint32_t stride, const double *h_actual, uint32_t n, int apply,
+                                      double *h_currents_out);
 /* copy the results of the last run (n_problems of them) to the host; synchronises the stream */
 int         mpc_hip_fetch_results(mpc_hip_handle *h, mpc_result *h_results, uint32_t n_problems);
 /* device address of the per-problem packed winners of the last run: for problem p two uint64,

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_abi_version", "mpc_hip_status_string", "mpc_hip_last_error", "mpc_hip_default_problem",
     "mpc_hip_substep_schedule", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
-    "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
+    "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
     "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
 )
 
@@ -76,6 +76,14 @@ class Plan(C.Structure):
     _fields_ = [("n_segments", C.c_int32), ("reserved", C.c_int32), ("segments", Dubins * MAX_PLAN_SEGMENTS)]
 
 
+CURRENT_MIN_SAMPLES, CURRENT_MAX_SAMPLES = 10, 600
+
+
+class HistorySample(C.Structure):
+    """one CurrentEstimator history entry: the State at an updateEstimate call + the controls in effect"""
+    _fields_ = [(n, C.c_double) for n in ("x", "y", "heading", "speed", "time", "rudder", "throttle")]
+
+
 class TreeLevel(C.Structure):
     _fields_ = [("n_leaves", C.c_uint64), ("best_leaf", C.c_uint64), ("best_score", C.c_double),
                 ("best_cumulative", C.c_double)]
@@ -124,6 +132,8 @@ def load_library(path=None):
     L.mpc_hip_combine_shards.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp]
     L.mpc_hip_upload_problems_from_plans.argtypes = [vp, PP, C.POINTER(u64), C.POINTER(Plan), dp, C.c_uint32]
     L.mpc_hip_fetch_checkpoints.argtypes = [vp, C.c_uint32, C.POINTER(Checkpoint)]
+    L.mpc_hip_estimate_currents.argtypes = [vp, C.POINTER(HistorySample), C.POINTER(C.c_uint32), C.c_uint32, dp, C.c_uint32,
+                                            i32, dp]
     L.mpc_hip_set_winner_sink.argtypes = [vp, vp]
     L.mpc_hip_set_timing.argtypes = [vp, C.c_uint32]
     L.mpc_hip_timing.argtypes = [vp, i32, C.POINTER(u64), dp, dp]
@@ -264,6 +274,22 @@ class Solver:
         out = (Checkpoint * depth)()
         _check(self._L.mpc_hip_fetch_checkpoints(self._h, int(problem), out))
         return [(c.x, c.y, c.heading, c.speed) for c in out]
+
+    def estimate_currents(self, histories, actual, apply=False):
+        """Batched CurrentEstimator::getCurrent on the device.  histories: per vessel a list of HistorySample (oldest
+        first) or of 7-tuples (x, y, heading, speed, time, rudder, throttle); actual: per vessel (x, y, time).
+        apply: the estimates become the resident problems' currents.  -> [(cx, cy)] per vessel."""
+        n = len(histories)
+        stride = max(1, max(len(hh) for hh in histories))
+        flat = (HistorySample * (n * stride))()
+        for p, hh in enumerate(histories):
+            for i, e in enumerate(hh):
+                flat[p * stride + i] = e if isinstance(e, HistorySample) else HistorySample(*[float(v) for v in e])
+        counts = (C.c_uint32 * n)(*[len(hh) for hh in histories])
+        act = (C.c_double * (3 * n))(*[float(v) for a3 in actual for v in a3])
+        out = (C.c_double * (2 * n))()
+        _check(self._L.mpc_hip_estimate_currents(self._h, flat, counts, stride, act, n, int(bool(apply)), out))
+        return [(out[2 * p], out[2 * p + 1]) for p in range(n)]
 
     def run_seeded(self, first, count, precision=PREC_FAST, selection=SELECT_LAST_STEP, d_cost_last=None,
                    d_cost_cum=None):

@@ -108,7 +108,7 @@ extern "C" void mpc_hip_destroy(mpc_hip_handle *h)
     (void)hipFree(h->d_results); (void)hipHostFree(h->h_results);
     (void)hipFree(h->d_winners); (void)hipFree(h->d_list_count); (void)hipFree(h->d_pcnt); (void)hipFree(h->d_snap);
     (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord); (void)hipFree(h->d_keys);
-    (void)hipFree(h->d_controls); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans);
+    (void)hipFree(h->d_controls); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
     mpc_tree_free(h);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);

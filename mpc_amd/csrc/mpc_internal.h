@@ -99,6 +99,7 @@ struct mpc_hip_handle {
     std::vector<int32_t> depth, nsub;
 
     void *d_plans = nullptr; size_t cap_plans = 0;              /* mpc_plan[P] + start times (mpc_plan.hip) */
+    void *d_hist = nullptr; size_t cap_hist = 0;                /* histories, counts, query states, estimates (mpc_current.hip) */
 
     /* tree search */
     std::vector<TreeLevelBuf> tree;

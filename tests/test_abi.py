@@ -55,6 +55,9 @@ def test_header_is_plain_c_and_constants_agree():
     assert int(re.search(r"#define MPC_MAX_SUBSTEPS (\d+)", text).group(1)) == M.MAX_SUBSTEPS
     assert int(re.search(r"#define MPC_MAX_PLAN_SEGMENTS (\d+)", text).group(1)) == M.binding.MAX_PLAN_SEGMENTS
     assert float(re.search(r"#define MPC_REFINE_REL ([0-9.eE+-]+)", text).group(1)) == M.REFINE_REL
+    assert int(re.search(r"#define MPC_CURRENT_MIN_SAMPLES (\d+)", text).group(1)) == M.binding.CURRENT_MIN_SAMPLES == 10
+    assert int(re.search(r"#define MPC_CURRENT_MAX_SAMPLES (\d+)", text).group(1)) == M.binding.CURRENT_MAX_SAMPLES == 600
+    assert C.sizeof(M.HistorySample) == 7 * 8            # mpc_history_sample: seven doubles, no padding
 
 
 def test_defaults_are_the_references():
