@@ -27,7 +27,7 @@ __device__ static inline void reckon(Reckoned &e, double rudder, double throttle
     while (t > 0) {
         const double d = t < 0.1 ? t : 0.1;
         t -= 0.1;
-        strict_level<SUB_STRIDE>(e.s, rudder, throttle, &d, 1, 0.0, 0.0);
+        strict_level<0>(e.s, rudder, throttle, &d, 1, 0.0, 0.0);            /* a bare dt, not a schedule row */
         e.time += d;
     }
 }

