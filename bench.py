@@ -246,7 +246,8 @@ def main():
         line = {
             "metric": "candidate_rollout_steps_per_sec",
             "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.workload == "config5" else "weak",     # config 5 splits a fixed 4096-vessel fleet
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
