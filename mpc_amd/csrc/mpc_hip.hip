@@ -180,6 +180,9 @@ void mpc_pack_problem(const mpc_problem *p, uint64_t seed, DevProblem *d)
     d->minr = p->min_rudder; d->midr = p->mid_rudder; d->maxr = p->max_rudder;
     d->mint = p->min_throttle; d->maxt = p->max_throttle; d->tol = p->tolerance;
     d->seed = seed; d->depth = p->depth; d->nsub = p->n_substeps;
+    d->head_uniform = p->n_substeps >= 2; d->pad0 = 0; d->pad1 = 0;
+    for (int s = 1; s + 1 < p->n_substeps; s++)
+        if (p->substeps[s] != p->substeps[0]) d->head_uniform = 0;
     double level_time = 0;
     for (int s = 0; s < p->n_substeps; s++) level_time += p->substeps[s];
     for (int l = 0; l < p->depth; l++) {

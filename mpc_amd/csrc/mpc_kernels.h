@@ -206,6 +206,7 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
         double cp[CP_STRIDE];
         cp[3] = cpv[3]; cp[4] = cpv[4]; cp[5] = cpv[5]; cp[6] = cpv[6]; cp[7] = cpv[7];
         if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub);
+        else if (P.head_uniform) fast_level_head_uniform(s, r, t, subL, P.nsub);
         else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub);
         last = fast_score(cp, s, w, q_last);
         cum += last;

@@ -292,6 +292,30 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
     s.rpm = fma(z.sgn, z.m, c.target_rpm);
 }
 
+/* Substeps 0 .. n_sub-2 equally long, the last one not (n_sub >= 2): what VehicleState::simulate itself produces
+ * (:48-54: steps of 0.1 s and a remainder; the 1-s level of controller.cpp:149 is ten of 0.1 s and one of 1.4e-16 s).
+ * The head runs like a uniform level (schedule row in registers, position in units of dt), the tail as one plain substep. */
+__device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
+{
+    const FastLevelCoef c = fast_level_coef(rudder, throttle);
+    FastSlew z = fast_slew_begin(s.rpm, c.target_rpm);
+    const double dt = sub[0], max_step = sub[1], dtm = sub[2], inv_dt = sub[5];
+    const double kpcm = c.kpc * dtm, dm = DRAG_COEFFICIENT * dtm, kyaw_dt = c.kyaw * dt;
+    double xs = s.x * inv_dt, ys = s.y * inv_dt;
+#ifdef MPC_SUBSTEP_UNROLL
+#pragma unroll MPC_SUBSTEP_UNROLL
+#endif
+    for (int k = 0; k < n_sub - 1; k++)
+        fast_substep<true>(z.m, s.v, s.sh, s.ch, xs, ys, z.sc, z.pst, max_step, kpcm, dm, kyaw_dt, dt);
+    s.x = xs * dt; s.y = ys * dt;
+    const double *q = sub + (n_sub - 1) * SUB_STRIDE;
+    const double dl = q[0];
+    fast_substep<false>(z.m, s.v, s.sh, s.ch, s.x, s.y, z.sc, z.pst, q[1], c.kpc * q[2], DRAG_COEFFICIENT * q[2],
+                        c.kyaw * dl, dl);
+    s.delta = s.v * dl;
+    s.rpm = fma(z.sgn, z.m, c.target_rpm);
+}
+
 /* tracking cost from the fast state; q_last = the schedule row of the level's last substep */
 __device__ inline double fast_score(const double *cp, const FastVeh &s, const Weights &w, const double *q_last)
 {
