@@ -78,6 +78,37 @@ MPC_MODEL_FN inline double div_known(double a, double b, double y)
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+/* sin and cos of a heading in [0, 2 pi) (what estimate()'s fmod leaves, VehicleState.h:129-132), branch-free: quadrant
+ * by Cody-Waite reduction with a two-part pi/2 (exact to ~2^-106 for k <= 4), then the fdlibm kernels on |r| <= pi/4
+ * (Sun's __kernel_sin / __kernel_cos minimax coefficients, < 1 ulp).  The library sincos carries a large-argument
+ * path behind a branch, which keeps the substep loop from being scheduled as one block; this is ~35 instructions and
+ * none.  Outside [0, 2 pi) (never produced by the model) the result is still sin/cos to ~1e-16 up to |h| ~ 1e5. */
+__device__ inline void heading_sincos(double h, double &sin_h, double &cos_h)
+{
+    const double kd = __builtin_rint(h * 0.63661977236758138243);           /* 2/pi */
+    double r = fma(-kd, 1.57079632679489655800e+00, h);                     /* RN(pi/2) */
+    r = fma(-kd, 6.12323399573676603587e-17, r);                            /* pi/2 - RN(pi/2) */
+    const int k = (int)kd;
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double s = fma(r * z, ps, r);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const double a = (k & 1) ? c : s, b = (k & 1) ? s : c;
+    sin_h = (k & 2) ? -a : a;
+    cos_h = ((k + 1) & 2) ? -b : b;
+}
+#endif
+
 /* One level: simulate()'s clamps (VehicleState.h:44-47) and n_sub estimate() calls (:111-148).
  * sin/cos of the rudder angle are loop invariant and cmg/sog are overwritten by every substep, so they are
  * evaluated once / for the last substep only: the values are the ones the reference ends the level with. */
@@ -122,7 +153,7 @@ MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, co
         const double delta = s.v * d_time;
 #if defined(__HIP_DEVICE_COMPILE__)
         double sin_h, cos_h;
-        sincos(h, &sin_h, &cos_h);          /* ocml: the same two results as sin() and cos(), one argument reduction */
+        heading_sincos(h, sin_h, cos_h);
 #else
         const double sin_h = sin(h), cos_h = cos(h);
 #endif
