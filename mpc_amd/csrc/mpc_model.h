@@ -140,11 +140,13 @@ MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, co
         const double rudder_speed_yaw = rudder_speed * sin_ra;
         const double yaw_rate = RUDDER_COEFFICIENT * rudder_speed_yaw / RUDDER_DISTANCE;
 
-        /* heading = fmod(heading + yaw_rate*dt, 2pi); if (< 0) += 2pi.  For an argument in [0, 4pi) the
-         * subtraction below is exact (Sterbenz) and therefore equals fmod; elsewhere call fmod. */
+        /* heading = fmod(heading + yaw_rate*dt, 2pi); if (< 0) += 2pi.  For an argument in (-2pi, 4pi) -- every
+         * substep of a real schedule -- fmod is an exact conditional subtraction (Sterbenz) or the identity, written as
+         * selects; anything else (and NaN) takes the one rare branch to fmod itself first. */
         double h = s.h + yaw_rate * d_time;
-        if (h >= TWO_PI) { h = (h < 2 * TWO_PI) ? h - TWO_PI : fmod(h, TWO_PI); }
-        else if (h < 0) { if (h <= -TWO_PI) h = fmod(h, TWO_PI); if (h < 0) h += TWO_PI; }
+        if (!(h > -TWO_PI && h < 2 * TWO_PI)) h = fmod(h, TWO_PI);
+        h = h >= TWO_PI ? h - TWO_PI : h;
+        h = h < 0 ? h + TWO_PI : h;
         s.h = h;
 
         const double speed = s.v;
