@@ -209,30 +209,73 @@ __device__ inline double fast_sqrt(double a)
     return fma(e, hh, g);
 }
 
+/* a*b + c as ONE three-address v_fma_f64.  For a Horner step with a constant addend hipcc emits v_mov_b64 (copy the
+ * constant) + v_fmac_f64 (accumulate into the copy).  On a lone wave those copies hide in dependent-issue bubbles; a
+ * full SIMD is VALU-bound and pays for every one of them.  Not volatile: the scheduler may still move them. */
+__device__ inline double fma3(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+/* LEAN chooses between the two spellings of a Horner step: the compiler's (mov + fmac) for kernels that run one wave
+ * per SIMD (config 2: 36.1 us vs 36.7 us with fma3), fma3 for launches that fill the SIMDs (4 M candidates: -2 %,
+ * tree expansion: -3 %).  The candidate-set kernels all use ONE spelling (the compiler's), so that a candidate's
+ * cost does not depend on the size of the set it came in; the tree expansion uses the lean one. */
+template <bool LEAN>
+__device__ inline double horner(double p, double x, double c) { return LEAN ? fma3(p, x, c) : fma(p, x, c); }
+
+/* exp(x) for the distance term, x >= 0: x = n ln2 + r, |r| <= ln2/2, Taylor to r^11 (3e-15 relative), scaled by 2^n.
+ * ldexp overflows to +inf like exp does (exp(5000) = inf keeps "no finite score" what it is); NaN stays NaN.
+ * 17 instructions against the library's ~38 (which also serve negative and subnormal results). */
+__device__ inline double fast_exp_nonneg(double x)
+{
+    x = fmin(x, 1024.0);                                   /* keeps n in int range; exp(1024) = inf already */
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(n, -6.93147180559945286227e-01, x);     /* RN(ln 2) */
+    r = fma(n, -2.31904681384629955842e-17, r);            /* ln 2 - RN(ln 2) */
+    double p = 1.0 / 39916800.0;
+    p = fma3(p, r, 1.0 / 3628800.0);
+    p = fma3(p, r, 1.0 / 362880.0);
+    p = fma3(p, r, 1.0 / 40320.0);
+    p = fma3(p, r, 1.0 / 5040.0);
+    p = fma3(p, r, 1.0 / 720.0);
+    p = fma3(p, r, 1.0 / 120.0);
+    p = fma3(p, r, 1.0 / 24.0);
+    p = fma3(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 /* Per-level constants of the fast model.  The rudder angle lies in [-pi/6, pi/6] (clamped rudder), so sin/cos need
  * no range reduction: Taylor polynomials to x^13 / x^14 (truncation < 1e-16 relative there) instead of the
  * library sincos with its reduction paths -- ~18 FMAs instead of ~70 instructions per level. */
 struct FastLevelCoef { double target_rpm, kpc, kyaw; };   /* thrust_fwd = kpc * (ps^2 - v^2);  yaw_rate = kyaw * rudder_speed */
 
+template <bool LEAN = false>
 __device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle)
 {
     rudder = fmin(fmax(rudder, -1.0), 1.0);
     throttle = fmin(fmax(throttle, 0.0), 1.0);
     const double x = rudder * MAX_RUDDER_ANGLE, x2 = x * x;
+    /* the two chains alternate in the source: inline asm (LEAN) keeps its source order */
     double ps = -1.0 / 6227020800.0;                                   /* -1/13! */
-    ps = fma(ps, x2, 1.0 / 39916800.0);
-    ps = fma(ps, x2, -1.0 / 362880.0);
-    ps = fma(ps, x2, 1.0 / 5040.0);
-    ps = fma(ps, x2, -1.0 / 120.0);
-    ps = fma(ps, x2, 1.0 / 6.0);
-    const double sin_ra = fma(-(x * x2), ps, x);
     double pc = -1.0 / 87178291200.0;                                  /* -1/14! */
-    pc = fma(pc, x2, 1.0 / 479001600.0);
-    pc = fma(pc, x2, -1.0 / 3628800.0);
-    pc = fma(pc, x2, 1.0 / 40320.0);
-    pc = fma(pc, x2, -1.0 / 720.0);
-    pc = fma(pc, x2, 1.0 / 24.0);
+    pc = horner<LEAN>(pc, x2, 1.0 / 479001600.0);
+    ps = horner<LEAN>(ps, x2, 1.0 / 39916800.0);
+    pc = horner<LEAN>(pc, x2, -1.0 / 3628800.0);
+    ps = horner<LEAN>(ps, x2, -1.0 / 362880.0);
+    pc = horner<LEAN>(pc, x2, 1.0 / 40320.0);
+    ps = horner<LEAN>(ps, x2, 1.0 / 5040.0);
+    pc = horner<LEAN>(pc, x2, -1.0 / 720.0);
+    ps = horner<LEAN>(ps, x2, -1.0 / 120.0);
+    pc = horner<LEAN>(pc, x2, 1.0 / 24.0);
+    ps = horner<LEAN>(ps, x2, 1.0 / 6.0);
     pc = fma(pc, x2, -0.5);
+    const double sin_ra = fma(-(x * x2), ps, x);
     const double cos_ra = fma(pc, x2, 1.0);
     return FastLevelCoef{throttle * MAX_RPM, PROP_COEFFICIENT * cos_ra, (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra};
 }
@@ -293,10 +336,10 @@ __device__ inline FastSlew fast_slew_begin(double rpm, double target_rpm)
 }
 
 /* STRIDE 0: every substep of the level uses schedule row 0 (held in registers by the caller) */
-template <int STRIDE = SUB_STRIDE>
+template <int STRIDE = SUB_STRIDE, bool LEAN = false>
 __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
 {
-    const FastLevelCoef c = fast_level_coef(rudder, throttle);
+    const FastLevelCoef c = fast_level_coef<LEAN>(rudder, throttle);
     FastSlew z = fast_slew_begin(s.rpm, c.target_rpm);
     if (STRIDE == 0) {
         const double dt = sub[0], max_step = sub[1], dtm = sub[2], inv_dt = sub[5];
@@ -328,9 +371,10 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
 /* Substeps 0 .. n_sub-2 equally long, the last one not (n_sub >= 2): what VehicleState::simulate itself produces
  * (:48-54: steps of 0.1 s and a remainder; the 1-s level of controller.cpp:149 is ten of 0.1 s and one of 1.4e-16 s).
  * The head runs like a uniform level (schedule row in registers, position in units of dt), the tail as one plain substep. */
+template <bool LEAN = false>
 __device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
 {
-    const FastLevelCoef c = fast_level_coef(rudder, throttle);
+    const FastLevelCoef c = fast_level_coef<LEAN>(rudder, throttle);
     FastSlew z = fast_slew_begin(s.rpm, c.target_rpm);
     const double dt = sub[0], max_step = sub[1], dtm = sub[2], inv_dt = sub[5];
     const double kpcm = c.kpc * dtm, dm = DRAG_COEFFICIENT * dtm, kyaw_dt = c.kyaw * dt;
@@ -350,6 +394,7 @@ __device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double
 }
 
 /* tracking cost from the fast state; q_last = the schedule row of the level's last substep */
+template <bool LEAN = false>
 __device__ inline double fast_score(const double *cp, const FastVeh &s, const Weights &w, const double *q_last)
 {
     /* the last substep's displacement over ground, VehicleState.h:139-140 */
@@ -363,7 +408,8 @@ __device__ inline double fast_score(const double *cp, const FastVeh &s, const We
     const double sog = fast_sqrt(fma(gdx, gdx, gdy * gdy)) * q_last[5];
     const double speed_diff = fabs(cp[3] - sog);
     const double ex = cp[6] - s.x, ey = cp[7] - s.y;
-    const double d = exp(fast_sqrt(fma(ex, ex, ey * ey)));
+    const double dist = fast_sqrt(fma(ex, ex, ey * ey));
+    const double d = LEAN ? fast_exp_nonneg(dist) : exp(dist);
     return fma(w.wd, d, fma(w.wh, heading_diff, w.ws * speed_diff));
 }
 

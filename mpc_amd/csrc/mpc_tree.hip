@@ -308,10 +308,10 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
     control_pick(P, A.last_r[par], A.last_t[par], j, ch.r, ch.t);
     ch.s.x = A.x[par]; ch.s.y = A.y[par]; ch.s.sh = A.h[par]; ch.s.ch = A.cmg[par]; ch.s.v = A.v[par]; ch.s.rpm = A.rpm[par];
     ch.s.delta = 0;
-    if (P.head_uniform) fast_level_head_uniform(ch.s, ch.r, ch.t, subL, P.nsub);      /* the reference's own 1-s level */
-    else fast_level<SUB_STRIDE>(ch.s, ch.r, ch.t, subL, P.nsub);
+    if (P.head_uniform) fast_level_head_uniform<true>(ch.s, ch.r, ch.t, subL, P.nsub);      /* the reference's own 1-s level */
+    else fast_level<SUB_STRIDE, true>(ch.s, ch.r, ch.t, subL, P.nsub);
     const Weights w{P.wd, P.wh, P.ws};
-    ch.score = fast_score(cpL + level * CP_STRIDE, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
+    ch.score = fast_score<true>(cpL + level * CP_STRIDE, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
     ch.cum = A.cum[par] + ch.score;
     ch.parent = par;
     return ch;
