@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing-period", type=int, default=8,
                     help="HIP events ride on every n-th solve's dispatches inside the timed region (1 = every solve)")
+    ap.add_argument("--combine-batch", type=int, default=64,
+                    help="solves per all-gather of the shard winners (multi-GPU runs)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -176,10 +178,10 @@ def main():
             offset, combine = 0, False                     # problems are sharded: no collective on the data path
             what = "BASELINE config 5: 4096 vessels (sharded over the GPUs) x 8,192 candidates x 20 s horizon"
         # non-negative doubles order like their bit patterns: (score bits, global ordinal) lexicographic minimum over
-        # the shards = the reference's first strict minimum.  One async all-gather per 16 solves (fewer, larger
+        # the shards = the reference's first strict minimum.  One async all-gather per --combine-batch solves (fewer, larger
         # collectives), reduced one batch later so that its latency hides behind rollouts (mpc_amd/distributed.py).
         combiner = ShardCombiner(solver, n_problems, ordinal_stride=(count if args.workload == "config2" else 0),
-                                 always=args.force_collective) if combine else None
+                                 always=args.force_collective, batch=args.combine_batch) if combine else None
 
         def step():
             if combiner:
@@ -255,7 +257,7 @@ def main():
                        "depth": depth, "substeps_per_level": nsub,
                        "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
                        "selection": "last_step",
-                       "parallelism": ("candidate shards; one async RCCL all-gather of the packed winners per 16 solves, reduced one batch later" if combine else
+                       "parallelism": ("candidate shards; one async RCCL all-gather of the packed winners per %d solves, reduced one batch later" % args.combine_batch if combine else
                                        ("problem shards, no collective" if world > 1 else "single GPU"))},
             "clock_ramp_s": args.ramp_seconds if args.workload == "config2" else 0.0,
             "p50_solve_latency_ms": p50,
