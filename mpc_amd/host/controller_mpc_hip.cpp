@@ -49,6 +49,8 @@ public:
         mpc_hip_handle* h = nullptr;
         const int s = mpc_hip_create(device, nullptr, &h);
         if (s != MPC_OK) throw std::runtime_error(std::string("mpc_hip_create: ") + mpc_hip_status_string(s) + ": " + mpc_hip_last_error());
+        /* a controller wants latency, not kernel timings: events on the dispatches cost ~30 us of a 90-us solve */
+        if (!std::getenv("MPC_HIP_TIMING")) mpc_hip_set_timing(h, 0);
         return h;
     }
     void release(mpc_hip_handle* h)
