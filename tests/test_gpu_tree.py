@@ -166,3 +166,26 @@ def test_sharded_search_equals_the_whole_search(solver, prec, n_shards, split):
     assert sum(r.evaluated for r, _ in shards) >= whole.evaluated           # the levels above the split are redundant
     with pytest.raises(M.MpcError):
         solver.solve_tree(p, depth, split_level=depth, shard=0, n_shards=2)  # the split level must be a stored level
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_tree_problems(solver, case):
+    """randomly drawn references, start states, currents, weights, last controls and granularities (fixed seed): the
+    same leaf counts, chosen leaves, scores and trajectories as the oracle's DFS at every deepening iteration, from
+    both expansions"""
+    rng = np.random.RandomState(500 + case)
+    depth = int(rng.randint(2, 5))
+    words = [(int(rng.randint(0, 6)), (float(rng.uniform(0.1, 1.2)), float(rng.uniform(3.3, 4.5)), float(rng.uniform(0.1, 1.2)))),
+             (W.LSL, (0.0, 10.0, 0.0))]
+    plan = W.chain(words, float(rng.uniform(6.0, 16.0)), float(rng.uniform(1.0, 2.75)),
+                   (float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50)), float(rng.uniform(0, 2 * math.pi))), 10.0)
+    x, y, heading, _ = plan.sample(10.0)
+    start = (x + float(rng.uniform(-2, 2)), y + float(rng.uniform(-2, 2)), (heading + float(rng.uniform(-0.5, 0.5))) % (2 * math.pi),
+             float(rng.uniform(0.0, 3.0)))
+    gr, gt = float(rng.choice([0.0625, 0.125, 0.03125])), float(rng.choice([0.125, 0.25, 0.0625]))
+    last = (float(rng.randint(-8, 9)) * gr, float(rng.randint(0, int(1 / gt) + 1)) * gt)
+    w = rng.uniform(0.5, 25.0, size=3)
+    p = M.make_problem(start, plan.checkpoints(10.0, depth), M.substep_schedule(1.0), last=last,
+                       current=(float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.6, 0.6))), weights=tuple(float(v) for v in w),
+                       rudder_granularity=gr, throttle_granularity=gt)
+    _check(solver, p, depth)
