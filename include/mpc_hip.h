@@ -243,7 +243,9 @@ int         mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, double 
  * every deepening iteration's argmin over last-step scores falls out of one expansion.
  * max_levels = maxIterations of controller.cpp:61 (<= problem depth).  now(ctx) / end_time reproduce the
  * deadline of :101-103 between levels (now == NULL: frozen clock, run all levels).  max_nodes bounds the
- * widest stored level (0 = library default); a level that does not fit ends the search like a deadline.
+ * widest level (a level that does not fit ends the search like a deadline).  0 = no budget: levels are stored up to
+ * the library's cap (2^28 nodes, 27 GB) and the first level beyond it -- depth 7 with the default control sets, 3e8
+ * leaves -- is still expanded, without stores, as the final one.
  * h_level_best: optional [max_levels] per-level winners (ordinal + scores) as the deepening loop saw them.
  * precision: MPC_PREC_F64 expands with the reference's arithmetic.  MPC_PREC_FAST expands with the streamlined model
  * and lets the reference's arithmetic decide: every leaf within MPC_REFINE_REL of a level's minimum is re-evaluated

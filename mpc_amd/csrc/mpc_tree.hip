@@ -602,6 +602,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
 {
     const bool fast = precision == MPC_PREC_FAST;
     memset(h_result, 0, sizeof *h_result);
+    const bool own_cap = max_nodes == 0;      /* no caller budget: the library's own storage cap */
     if (max_nodes == 0) max_nodes = 1ull << 28;
     if (max_nodes > 0xFFFFFFF0ull) max_nodes = 0xFFFFFFF0ull;
     if (int s = mpc_hip_upload_problems(h, h_problem, nullptr, 1)) return s;
@@ -653,12 +654,15 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_scan_tmp + ntile, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         memcpy(tot, h->h_pair, sizeof tot);
-        if (tot[1] != 0 || tot[0] > max_nodes) break;                     /* does not fit: stop like a deadline */
+        /* a level wider than the caller's budget (or than 32-bit ordinals) ends the search like a deadline; one that is
+         * only wider than the library's own storage cap is still expanded -- without stores, as the final level */
+        const bool too_wide = tot[0] > max_nodes;
+        if (tot[1] != 0 || (too_wide && !own_cap)) break;
         const uint32_t nchild = tot[0];
         TreeLevelBuf &B = h->tree[it + 1];
         /* the last level asked for is never a parent level: expanded without stores (strict: into a one-node buffer
          * that receives the winner's record; fast: the winner comes from its path) */
-        const bool stored = it + 1 < max_levels;
+        const bool stored = it + 1 < max_levels && !too_wide;
         B.first = 0;
         if (int s = ensure_level(h, B, stored ? nchild : 1)) {
             if (s == MPC_ERR_HIP) { (void)hipGetLastError(); break; }     /* out of memory: stop like a deadline */
@@ -717,6 +721,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             B.n = (size_t)(base + (shard < extra ? 1 : 0));
             if (int s = publish_level(h, it + 1)) return s;
         }
+        if (!stored) break;                                              /* nothing to expand the next level from */
     }
     HIP_TRY(hipEventRecord(ev[1], h->stream));
     if (overflow) {

@@ -189,3 +189,16 @@ def test_random_tree_problems(solver, case):
                        current=(float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.6, 0.6))), weights=tuple(float(v) for v in w),
                        rudder_granularity=gr, throttle_granularity=gt)
     _check(solver, p, depth)
+
+
+def test_the_first_level_beyond_the_storage_cap_is_the_final_one(solver):
+    """no node budget and more levels asked for than fit: levels are stored up to the library's cap (2^28 nodes) and the
+    first level beyond it -- depth 7, 3.0e8 leaves -- is expanded without stores; the answer is the depth-7 search's"""
+    q, _plan = W.config1_problem(depth=8)
+    assert q.depth == 8
+    for prec in (M.PREC_FAST, M.PREC_F64):
+        deep, dl = solver.solve_tree(q, 8, precision=prec)
+        ref, rl = solver.solve_tree(q, 7, precision=prec)
+        assert deep.levels == ref.levels == 7 and dl[6].n_leaves == 303370833
+        assert (deep.best_ordinal, deep.best_last, deep.best_cumulative) == (ref.best_ordinal, ref.best_last, ref.best_cumulative)
+        assert traj_array(deep).tobytes() == traj_array(ref).tobytes()
