@@ -1,0 +1,48 @@
+"""Determinism soak on the GPU: 20,000 config-2 solves, 150 tree searches per expansion and 50 fleet batches must each give\none result, bit for bit (races in the staging / argmin / finish paths would show up as stray winners).  python tools/soak.py"""
+import sys
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, mpc_amd as M
+from mpc_amd import workloads as W
+depth, count = 20, 65536
+stream = torch.cuda.Stream()
+with torch.cuda.stream(stream):
+    s = M.Solver(0, stream=stream.cuda_stream); s.set_timing(0)
+    prob = W.config2_problem(depth)
+    r, t = W.seeded_controls(W.SEED, 0, count, depth, prob.last_rudder, prob.last_throttle)
+    d_r = torch.tensor(r, dtype=torch.float32, device="cuda"); d_t = torch.tensor(t, dtype=torch.float32, device="cuda")
+    d_last = torch.empty(count, dtype=torch.float64, device="cuda"); d_cum = torch.empty(count, dtype=torch.float64, device="cuda")
+    s.upload([prob], [W.SEED])
+    N = 20000
+    sink = torch.zeros(2 * N, dtype=torch.int64, device="cuda")
+    ref_last = None
+    for i in range(N):
+        s.set_winner_sink(sink[2 * i:2 * i + 2])
+        s.run_candidates(d_r, d_t, count, M.PREC_FAST, M.SELECT_LAST_STEP, d_last, d_cum)
+        if i % 5000 == 0:
+            torch.cuda.synchronize()
+            cur = d_last.clone()
+            if ref_last is None: ref_last = cur
+            assert torch.equal(cur, ref_last), i
+    s.set_winner_sink(None)
+    torch.cuda.synchronize()
+    w = sink.view(N, 2).cpu().numpy()
+    print("config2 x", N, "distinct winners:", len(np.unique(w, axis=0)), w[0], flush=True)
+    assert len(np.unique(w, axis=0)) == 1
+    # tree, both expansions
+    q, _ = W.config1_problem(depth=6)
+    for prec in (M.PREC_FAST, M.PREC_F64):
+        seen = set()
+        for i in range(150):
+            res, lv = s.solve_tree(q, 6, precision=prec)
+            seen.add((res.best_ordinal, res.best_last, res.best_cumulative, tuple(l.best_leaf for l in lv[:6])))
+        print("tree prec", prec, "x150 distinct results:", len(seen), flush=True)
+        assert len(seen) == 1
+    # fleet batch
+    probs, seeds = W.fleet_problems(256, 20)
+    seen = set()
+    for i in range(50):
+        res = s.eval_seeded_batch(probs, seeds, 8192, M.PREC_FAST)
+        seen.add(tuple((r.best_ordinal, r.best_last) for r in res))
+    print("fleet 256 x 8192 x50 distinct results:", len(seen), flush=True)
+    assert len(seen) == 1
+print("soak ok")
