@@ -1,4 +1,5 @@
-"""Determinism soak on the GPU: 20,000 config-2 solves, 150 tree searches per expansion and 50 fleet batches must each give\none result, bit for bit (races in the staging / argmin / finish paths would show up as stray winners).  python tools/soak.py"""
+"""Determinism soak on the GPU: 20,000 config-2 solves, 150 tree searches per expansion and 50 fleet batches must each give
+one result, bit for bit (races in the staging / argmin / finish paths would show up as stray winners).  python tools/soak.py"""
 import sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, mpc_amd as M
