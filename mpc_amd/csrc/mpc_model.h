@@ -27,6 +27,17 @@
 #define CP_STRIDE 8
 #define SUB_STRIDE 6
 
+/* Host builds of the strict model keep IEEE semantics whatever the including project's flags are: the reference builds
+ * with -funsafe-math-optimizations (CMakeLists.txt:4), which lets g++ reassociate sums and turn divisions into
+ * multiplications by reciprocals -- the host VehicleState of mpc_amd/host would then differ from the device's strict
+ * kernels (and from the oracle) in the last bits.  Functions compiled under these options are not inlined into
+ * callers compiled under others, so the arithmetic below stays as written. */
+#if !defined(__HIPCC__) && defined(__GNUC__) && !defined(__clang__)
+#pragma GCC push_options
+#pragma GCC optimize("no-unsafe-math-optimizations", "no-fast-math", "fp-contract=off")
+#define MPC_MODEL_HOST_STRICT_OPTIONS 1
+#endif
+
 namespace mpc {
 
 /* model constants, VehicleState.h:86-101 */
@@ -416,4 +427,8 @@ __device__ inline double fast_score(const double *cp, const FastVeh &s, const We
 #endif /* __HIPCC__ */
 
 }  // namespace mpc
+
+#if defined(MPC_MODEL_HOST_STRICT_OPTIONS)
+#pragma GCC pop_options
+#endif
 #endif

@@ -27,6 +27,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "controller.h"
@@ -79,10 +80,14 @@ struct Lease {
 
 /* what the between-levels callback needs: the clock, the deadline, and the cancellation test */
 struct PollContext {
+    /* a constructor rather than brace initialisation: the reference builds with -std=c++11 (CMakeLists.txt:6), where
+     * a struct with a default member initialiser is not an aggregate */
+    PollContext(const ControlReceiver* r, double end, std::function<bool()> valid)
+        : receiver(r), endTime(end), stillValid(std::move(valid)), cancelled(false) {}
     const ControlReceiver* receiver;
     double endTime;
     std::function<bool()> stillValid;
-    bool cancelled = false;
+    bool cancelled;
 };
 
 double poll(void* p)
@@ -130,7 +135,7 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
     }
     problem.n_substeps = mpc_hip_substep_schedule(c_ScoringTimeStep, problem.substeps, MPC_MAX_SUBSTEPS);   /* VehicleState.h:49-53 */
 
-    PollContext ctx{m_ControlReceiver, endTime, [this, trajectoryNumber] { return validTrajectoryNumber(trajectoryNumber); }};
+    PollContext ctx(m_ControlReceiver, endTime, [this, trajectoryNumber] { return validTrajectoryNumber(trajectoryNumber); });
     mpc_result result;
     int status;
     {
