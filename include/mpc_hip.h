@@ -169,6 +169,23 @@ int         mpc_hip_run_seeded(mpc_hip_handle *h, uint64_t first_ordinal, uint64
 int         mpc_hip_run_candidates(mpc_hip_handle *h, const float *d_rudders, const float *d_throttles,
                                    uint64_t n, int precision, int selection,
                                    double *d_cost_last, double *d_cost_cum);
+/* mpc_hip_run_seeded for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (it has no device): this entry
+ * point exists for callers that must not reach hipMalloc / hipFree -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid allocation.  Same arguments, same kernels, same results in the same places
+ * (mpc_hip_fetch_results, device winners, winner sink, d_cost_*) as mpc_hip_run_seeded, bit for bit; what differs is
+ * where the working memory lives: the candidates' keys and the rollout workgroups' (key, ordinal, near-tie count)
+ * triples are kept in a fixed device array inside the library (8.6 MB, held by every GPU the library has created a
+ * handle on until the process ends) instead of grow-on-demand buffers of the handle, and no per-level snapshots are
+ * written (the winner's trajectory is rolled out once more on one lane).  The call performs no hipMalloc, hipFree or
+ * other allocating call; problems must have been uploaded before (mpc_hip_upload_problems allocates).
+ * Limits: resident problems x count <= MPC_STATIC_MAX_CANDIDATES and problems x rollout workgroups (64 candidates
+ * each below 2^20 candidates in total, 256 at it) <= MPC_STATIC_MAX_WORKGROUPS; beyond -> MPC_ERR_TOO_LARGE, nothing
+ * launched.  All handles on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads)
+ * race -- serialise them; nothing in the array needs clearing between calls (every word read is written first). */
+#define MPC_STATIC_MAX_CANDIDATES (1u << 20)
+#define MPC_STATIC_MAX_WORKGROUPS (1u << 15)
+int         mpc_hip_run_seeded_static(mpc_hip_handle *h, uint64_t first_ordinal, uint64_t count, int precision,
+                                      int selection, double *d_cost_last, double *d_cost_cum);
 /* Reference trajectories sampled on the device.  Replaces, for batches, the host loop of
  * controller.cpp:96-98 -- checkpoint i = referenceTrajectory.sample(start time + (i+1) * 1 s) -- with one kernel
  * (a lane per problem and level) that writes the checkpoints into the resident problem records; the problems' own

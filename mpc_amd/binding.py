@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_abi_version", "mpc_hip_status_string", "mpc_hip_last_error", "mpc_hip_default_problem",
     "mpc_hip_substep_schedule", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
-    "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_run_seeded", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
+    "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_run_seeded", "mpc_hip_run_seeded_static", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
     "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
 )
 
@@ -125,6 +125,7 @@ def load_library(path=None):
     L.mpc_hip_eval_seeded_batch.argtypes = [vp, PP, C.POINTER(u64), C.c_uint32, u64, i32, i32, vp, vp, RP]
     L.mpc_hip_upload_problems.argtypes = [vp, PP, C.POINTER(u64), C.c_uint32]
     L.mpc_hip_run_seeded.argtypes = [vp, u64, u64, i32, i32, vp, vp]
+    L.mpc_hip_run_seeded_static.argtypes = [vp, u64, u64, i32, i32, vp, vp]
     L.mpc_hip_run_candidates.argtypes = [vp, vp, vp, u64, i32, i32, vp, vp]
     L.mpc_hip_fetch_results.argtypes = [vp, RP, C.c_uint32]
     L.mpc_hip_device_winners.argtypes = [vp, C.POINTER(vp)]
@@ -295,6 +296,12 @@ class Solver:
                    d_cost_cum=None):
         _check(self._L.mpc_hip_run_seeded(self._h, first, count, precision, selection, _ptr(d_cost_last),
                                           _ptr(d_cost_cum)))
+
+    def run_seeded_static(self, first, count, precision=PREC_FAST, selection=SELECT_LAST_STEP, d_cost_last=None,
+                          d_cost_cum=None):
+        """run_seeded with the library's fixed device array as working memory: allocates nothing (mpc_hip.h)"""
+        _check(self._L.mpc_hip_run_seeded_static(self._h, first, count, precision, selection, _ptr(d_cost_last),
+                                                 _ptr(d_cost_cum)))
 
     def run_candidates(self, d_rudders, d_throttles, n, precision=PREC_FAST, selection=SELECT_LAST_STEP,
                        d_cost_last=None, d_cost_cum=None):

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include <hip/hip_ext.h>
 
@@ -22,6 +23,39 @@
 
 static thread_local char g_err[512] = "";
 void mpc_set_err(const char *fmt, const char *a, const char *b) { snprintf(g_err, sizeof g_err, fmt, a, b); }
+
+/* ---- working memory of mpc_hip_run_seeded_static (the entry point that allocates nothing) -----------------------
+ * What run_common() otherwise keeps in hipMalloc'ed, grow-on-demand buffers of the handle -- the candidates' keys
+ * and the K1 workgroup triples -- laid out in ONE file-scope device array of fixed size (8.6 MB, held by every GPU
+ * the library runs on until the process ends).  `scratch` is a host-side stand-in for the symbol, not a device
+ * address: host code only ever uses the per-device address hipGetSymbolAddress returned (static_scratch_ptr(),
+ * resolved in mpc_hip_create with that device current; each GPU holds its own copy at its own address). */
+struct StaticScratch {
+    double   keys[MPC_STATIC_MAX_CANDIDATES];
+    uint64_t pkey[MPC_STATIC_MAX_WORKGROUPS];
+    uint64_t pord[MPC_STATIC_MAX_WORKGROUPS];
+    uint32_t pcnt[MPC_STATIC_MAX_WORKGROUPS];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
+
+#define MPC_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[MPC_MAX_DEVICES];          /* per device: the address of ITS copy of scratch[] */
+
+/* device must be current */
+static int static_scratch_ptr(int device, void **out)
+{
+    if (device < 0 || device >= MPC_MAX_DEVICES) { mpc_set_err("device index beyond MPC_MAX_DEVICES"); return MPC_ERR_NO_DEVICE; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) { mpc_set_err("hipGetSymbolAddress(scratch) returned a null address"); return MPC_ERR_HIP; }
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return MPC_OK;
+}
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* host side                                                                                               */
@@ -92,6 +126,7 @@ extern "C" int mpc_hip_create(int device, void *stream, mpc_hip_handle **out)
         for (auto &e : h->ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipMalloc(&h->d_controls, sizeof(double) * 2 * MPC_MAX_DEPTH));
         HIP_TRY(hipHostMalloc(&h->h_pair, sizeof(uint64_t) * 8));
+        if (int s2 = static_scratch_ptr(device, &h->d_static_scratch)) return s2;
         return MPC_OK;
     }();
     if (s != MPC_OK) { mpc_hip_destroy(h); return s; }       /* nothing of a half-built handle leaks */
@@ -231,8 +266,11 @@ static int ensure_keys(mpc_hip_handle *h, size_t need)
     return MPC_OK;
 }
 
+/* use_static: working memory = the device's scratch[] instead of the handle's own buffers, no snapshots; the call
+ * then allocates (and frees) nothing and rejects sets beyond the array's fixed capacity */
 static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const float *d_thr, uint64_t first,
-                      uint64_t count, int precision, int selection, double *d_cost_last, double *d_cost_cum)
+                      uint64_t count, int precision, int selection, double *d_cost_last, double *d_cost_cum,
+                      bool use_static = false)
 {
     if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
     if (h->n_probs == 0) { mpc_set_err("no problems uploaded"); return MPC_ERR_INVALID; }
@@ -257,8 +295,24 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     const uint64_t nblk64 = (count + cpb - 1) / cpb;
     if (nblk64 > 0x7FFFFFFFull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
     const uint32_t nblk = (uint32_t)nblk64;
-    if (int s = ensure_keys(h, (size_t)h->n_probs * count)) return s;
-    if (int s = mpc_ensure_partials(h, (size_t)h->n_probs * nblk)) return s;
+    double *d_keys; uint64_t *d_pkey, *d_pord; uint32_t *d_pcnt;
+    if (use_static) {
+        if ((uint64_t)h->n_probs * count > MPC_STATIC_MAX_CANDIDATES) {
+            mpc_set_err("run_seeded_static: problems x candidates exceeds MPC_STATIC_MAX_CANDIDATES (2^20); use mpc_hip_run_seeded");
+            return MPC_ERR_TOO_LARGE;
+        }
+        if ((uint64_t)h->n_probs * nblk > MPC_STATIC_MAX_WORKGROUPS) {
+            mpc_set_err("run_seeded_static: problems x workgroups exceeds MPC_STATIC_MAX_WORKGROUPS (2^15); use mpc_hip_run_seeded");
+            return MPC_ERR_TOO_LARGE;
+        }
+        if (!h->d_static_scratch) { mpc_set_err("run_seeded_static: the device's scratch address is not resolved"); return MPC_ERR_HIP; }
+        StaticScratch *S = (StaticScratch *)h->d_static_scratch;       /* the device address, never the symbol's name */
+        d_keys = S->keys; d_pkey = S->pkey; d_pord = S->pord; d_pcnt = S->pcnt;
+    } else {
+        if (int s = ensure_keys(h, (size_t)h->n_probs * count)) return s;
+        if (int s = mpc_ensure_partials(h, (size_t)h->n_probs * nblk)) return s;
+        d_keys = h->d_keys; d_pkey = h->d_pkey; d_pord = h->d_pord; d_pcnt = h->d_pcnt;
+    }
 
     /* per-level snapshots of every candidate (so the winner's trajectory needs no second rollout) while they
      * stay small; beyond that the winner is rolled out again by one lane, which is then noise */
@@ -266,7 +320,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     for (uint32_t p = 0; p < h->n_probs; p++) snap_depth = std::max(snap_depth, (int)h->depth[p]);
     const size_t snap_need = (size_t)h->n_probs * count * snap_depth * SNAP_FIELDS;
     double *d_snap = nullptr;
-    if (snap_need * sizeof(double) <= MPC_SNAPSHOT_BYTES_MAX) {
+    if (!use_static && snap_need * sizeof(double) <= MPC_SNAPSHOT_BYTES_MAX) {
         if (snap_need > h->cap_snap) {
             HIP_TRY(hipStreamSynchronize(h->stream));
             (void)hipFree(h->d_snap); h->d_snap = nullptr; h->cap_snap = 0;
@@ -297,8 +351,8 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     if (uniform) LAUNCH_K1U(PREC, SEEDED, true); else LAUNCH_K1U(PREC, SEEDED, false)
 #define LAUNCH_K1U(PREC, SEEDED, UNI)                                                                         \
     hipExtLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, rel, d_cost_last, d_cost_cum, h->d_keys, d_snap, snap_depth,  \
-                       h->d_pkey, h->d_pord, h->d_pcnt)
+                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth,  \
+                       d_pkey, d_pord, d_pcnt)
     if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
     else { if (seeded) LAUNCH_K1(MPC_PREC_FAST, true); else LAUNCH_K1(MPC_PREC_FAST, false); }
 #undef LAUNCH_K1
@@ -306,7 +360,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     HIP_TRY(hipGetLastError());
 #define LAUNCH_K2(SEEDED)                                                                                     \
     hipExtLaunchKernelGGL((finish_kernel<SEEDED>), dim3(h->n_probs), dim3(256), 0, h->stream, k2a, k2b, 0, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, fast, (int)uniform, rel, nblk, cpb, h->d_pkey, h->d_pord, h->d_pcnt, h->d_keys, \
+                       first, count, selection, fast, (int)uniform, rel, nblk, cpb, d_pkey, d_pord, d_pcnt, d_keys, \
                        d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->d_results)
     if (seeded) LAUNCH_K2(true); else LAUNCH_K2(false);
 #undef LAUNCH_K2
@@ -327,6 +381,15 @@ extern "C" int mpc_hip_run_candidates(mpc_hip_handle *h, const float *d_rudders,
                                       uint64_t n, int precision, int selection, double *d_cost_last, double *d_cost_cum)
 {
     return run_common(h, false, d_rudders, d_throttles, 0, n, precision, selection, d_cost_last, d_cost_cum);
+}
+
+/* mpc_hip_run_seeded without any allocation: K1's keys and workgroup triples live in the device's scratch[] (nothing in
+ * it has to start at zero: K1 writes every word K2 reads), there are no per-level snapshots (K2 rolls the winner out
+ * again on one lane -- the same arithmetic, the same bits), results go where mpc_hip_run_seeded puts them. */
+extern "C" int mpc_hip_run_seeded_static(mpc_hip_handle *h, uint64_t first_ordinal, uint64_t count, int precision,
+                                         int selection, double *d_cost_last, double *d_cost_cum)
+{
+    return run_common(h, true, nullptr, nullptr, first_ordinal, count, precision, selection, d_cost_last, d_cost_cum, true);
 }
 
 extern "C" int mpc_hip_set_timing(mpc_hip_handle *h, uint32_t period)

@@ -94,6 +94,7 @@ struct mpc_hip_handle {
     double *d_keys = nullptr;
     size_t cap_keys = 0;
     double *d_controls = nullptr;                               /* 2 * MPC_MAX_DEPTH, mpc_hip_rollout */
+    void *d_static_scratch = nullptr;                           /* this device's copy of scratch[] (mpc_hip.hip), not owned */
 
     uint64_t last_count = 0, last_first = 0;
     int last_precision = 0, last_selection = 0, last_seeded = 0;
