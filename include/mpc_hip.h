@@ -82,7 +82,8 @@ typedef struct {
     double start_x, start_y, start_heading, start_speed;   /* startState (rpm derived, VehicleState.h:21)    */
     double last_rudder, last_throttle;                      /* m_LastRudder / m_LastThrottle, controller.cpp:71-72 */
     double current_x, current_y;                            /* m_DisturbanceEstimate, controller.cpp:150       */
-    double w_distance, w_heading, w_speed;                  /* controller.cpp:240                              */
+    double w_distance, w_heading, w_speed;                  /* controller.cpp:240; must be finite and >= 0 (the
+                                                             * ranges of cfg/mpc.cfg:11-15), else MPC_ERR_INVALID */
     double rudder_granularity, throttle_granularity;        /* controller.cpp:43-44 (tree search only)         */
     double min_rudder, mid_rudder, max_rudder;              /* controller.h:146                                */
     double min_throttle, max_throttle;                      /* controller.h:147                                */

@@ -195,6 +195,11 @@ int mpc_check_problem(const mpc_problem *p, int precision)
 {
     if (p->depth < 1 || p->depth > MPC_MAX_DEPTH) { mpc_set_err("problem depth out of range [1, MPC_MAX_DEPTH]"); return MPC_ERR_TOO_LARGE; }
     if (p->n_substeps < 1 || p->n_substeps > MPC_MAX_SUBSTEPS) { mpc_set_err("problem n_substeps out of range [1, MPC_MAX_SUBSTEPS]"); return MPC_ERR_TOO_LARGE; }
+    /* scores are compared through their bit patterns (key_of), which orders non-negative doubles only: the cost of
+     * controller.cpp:240 is >= 0 exactly when its weights are (cfg/mpc.cfg:11-15 allows [0, 10], [0, 60], [0, 10]) */
+    const double w[3] = {p->w_distance, p->w_heading, p->w_speed};
+    for (double v : w)
+        if (!(v >= 0.0) || !isfinite(v)) { mpc_set_err("weights must be finite and >= 0 (cfg/mpc.cfg:11-15)"); return MPC_ERR_INVALID; }
     for (int s = 0; s < p->n_substeps; s++) {
         if (!(p->substeps[s] > 0)) { mpc_set_err("substep lengths must be > 0"); return MPC_ERR_INVALID; }
         if (precision == MPC_PREC_FAST && p->substeps[s] > 0.1000001) {
@@ -256,6 +261,10 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
     return MPC_OK;
 }
 
+/* dynamic LDS of K1 without staged controls (checkpoints + schedule + argmin words), and what one launch may ask for */
+#define K1_LDS_BASE (sizeof(double) * (MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + sizeof(uint64_t) * 12)
+#define K1_LDS_LIMIT ((size_t)64 * 1024)
+
 static int ensure_keys(mpc_hip_handle *h, size_t need)
 {
     if (need <= h->cap_keys) return MPC_OK;
@@ -290,7 +299,10 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
                 }
     /* one wave per workgroup while the set is small (spreads the waves over all SIMDs), 256 lanes otherwise */
     uint32_t block = (count * h->n_probs >= (1u << 20)) ? 256u : 64u;
-    if (!seeded && h->depth[0] > 32) block = 64;    /* keeps the staged controls (2 * depth * block floats) <= 32 KiB */
+    /* explicit sets stage 2 * depth * block FP32 controls in LDS next to the 7.3 KB of problem data: the workgroup
+     * shrinks until that fits the 64 KiB a launch gets without opting in to more (256 lanes up to depth 28, 128 up to
+     * depth 56, 64 beyond: 39.3 KiB at MPC_MAX_DEPTH).  A candidate's cost does not depend on its workgroup's size. */
+    while (!seeded && block > 64 && K1_LDS_BASE + sizeof(float) * 2 * (size_t)h->depth[0] * block > K1_LDS_LIMIT) block >>= 1;
     const uint32_t cpb = block;                   /* candidates per workgroup */
     const uint64_t nblk64 = (count + cpb - 1) / cpb;
     if (nblk64 > 0x7FFFFFFFull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
@@ -340,7 +352,8 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     const dim3 grid(nblk, h->n_probs), blk(block);
     /* explicit sets: all levels' controls of a workgroup are staged in LDS as FP32 (<= 64 KiB by the block choice) */
     const size_t ctl_bytes = seeded ? 0 : sizeof(float) * 2 * (size_t)snap_depth * block;
-    const size_t lds = sizeof(double) * (MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + sizeof(uint64_t) * 12 + ctl_bytes;
+    const size_t lds = K1_LDS_BASE + ctl_bytes;
+    if (lds > K1_LDS_LIMIT) { mpc_set_err("rollout kernel: staged controls do not fit the workgroup's LDS"); return MPC_ERR_TOO_LARGE; }
     /* timed runs carry their events ON the two dispatches (the kernels' own begin/end, as a profiler reads them):
      * recording events between the launches instead costs ~4 barrier packets = 15 us per 59-us solve */
     const bool timed = h->timing_period && (h->runs % h->timing_period) == 0;

@@ -739,9 +739,16 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         hipLaunchKernelGGL(path_trace_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, h->d_level_ptrs, completed - 1,
                            (uint32_t)h->tree[completed - 1].n, (uint32_t)best_leaf, h->d_results);
     } else {
-        for (int l = completed; l >= 0; l--)
-            hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(h->tree[l]), l, completed,
+        for (int l = completed; l >= 0; l--) {
+            /* best_leaf indexes level `completed` as it was EXPANDED -- whole, from the buffer's start.  A sharded search
+             * that ends at its split level has sliced that level since (first != 0 for shard > 0): the leaf is looked up
+             * in the unsliced view.  Levels above it are reached through parent links, which are relative to the view
+             * their children were expanded from (the sliced one below a split level): ptrs() as it stands. */
+            TreeLevelBuf view = h->tree[l];
+            if (l == completed) view.first = 0;
+            hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(view), l, completed,
                                (uint32_t)best_leaf, leaf_stored ? (uint32_t)best_leaf : 0u, h->d_list_count, h->d_results);
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], h->stream));

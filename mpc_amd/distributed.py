@@ -225,11 +225,13 @@ def combine_tree_levels(gathered, split_level):
         prefix = np.concatenate([[0], np.cumsum(g[:, l, 0])[:-1]])
         best = None
         for s in range(n_shards):
-            if g[s, l, 0] == 0:
+            if g[s, l, 0] == 0 or g[s, l, 2] == -1:        # no leaves / no leaf with a finite score in this shard
                 continue
             cand = (int(g[s, l, 1]), int(prefix[s] + g[s, l, 2]), s)          # non-negative scores order like their bits
             if best is None or cand[:2] < best[:2]:
                 best = cand
+        if best is None:                                   # nothing selected at this level anywhere
+            best = (int(np.float64(np.inf).view(np.int64)), -1, 0)
         out.append((int(g[:, l, 0].sum()), best[1], best[0], best[2]))
     return out
 
@@ -242,7 +244,14 @@ def solve_tree_sharded(solver, problem, max_levels, split_level, precision=1, gr
     rank = dist.get_rank(group) if on else 0
     res, levels = solver.solve_tree(problem, max_levels, precision, split_level=split_level, shard=rank, n_shards=world)
     dev = "cuda" if on and dist.get_backend(group) == "nccl" else "cpu"
-    mine = tree_levels_tensor(levels, res.levels, dev)
+    n_levels = int(res.levels)
+    if world > 1:
+        # shards expand slices of different widths: a node budget, the storage cap or memory can stop them at different
+        # depths.  Only the levels EVERY shard completed can be combined (and the gather needs equal shapes).
+        common = torch.tensor([n_levels], dtype=torch.int64, device=dev)
+        dist.all_reduce(common, op=dist.ReduceOp.MIN, group=group)
+        n_levels = int(common.item())
+    mine = tree_levels_tensor(levels, n_levels, dev).view(n_levels, 3)
     if world > 1:
         gathered = torch.empty((world,) + tuple(mine.shape), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)

@@ -41,6 +41,7 @@ public:
             const double d = t < 0.1 ? t : 0.1;
             t -= 0.1;
             rows[n * SUB_STRIDE] = d;
+            rows[n * SUB_STRIDE + 5] = 1.0 / d;          /* the schedule row's reciprocal slot (the device's div_known reads it) */
             elapsed += d;
             if (++n == kMaxSubsteps) { mpc::strict_level(v, rudder, throttle, rows, n, estimatedCurrent.first, estimatedCurrent.second); n = 0; }
         }

@@ -142,3 +142,48 @@ def test_everything_ties(solver):
         assert res.levels == 4 and res.best_ordinal == 0
         assert [levels[l].best_leaf for l in range(4)] == [0, 0, 0, 0]
         assert (res.first_rudder, res.first_throttle) == (q.min_rudder, q.min_throttle)     # first child: (minR, minT)
+
+
+@pytest.mark.parametrize("depth", [28, 29, 32, 57])
+def test_a_million_explicit_candidates_at_the_lds_bound(solver, depth):
+    """>= 2^20 explicit candidates run 256-lane workgroups, whose staged controls (2 * depth * 256 floats) plus the
+    7.3 KB of problem data pass 64 KiB of LDS from depth 29 on: the library then halves the workgroup (128 lanes up to
+    depth 56, 64 beyond).  4096 distinct control sequences tiled 256 times, all checked against the oracle; the first
+    occurrence of the best sequence wins."""
+    torch = _torch()
+    p = _circle_problem(depth, W.uniform_substeps())
+    base, reps = 4096, 256
+    n = base * reps
+    rud, thr = W.seeded_controls(W.SEED + depth, 0, base, depth, p.last_rudder, p.last_throttle)
+    rud32, thr32 = rud.astype(np.float32), thr.astype(np.float32)
+    d_rud = torch.tensor(rud32, device="cuda").repeat(1, reps).contiguous()           # [depth][n]: lane i = sequence i % 4096
+    d_thr = torch.tensor(thr32, device="cuda").repeat(1, reps).contiguous()
+    o_last, o_cum, o_best = oracle_explicit(p, rud32.astype(np.float64), thr32.astype(np.float64))
+    last = torch.empty(n, dtype=torch.float64, device="cuda")
+    cum = torch.empty(n, dtype=torch.float64, device="cuda")
+    res = solver.eval_candidates(p, d_rud, d_thr, n, M.PREC_FAST, M.SELECT_LAST_STEP, last, cum)
+    got = last.cpu().numpy().reshape(reps, base)
+    assert (got == got[0]).all()                                 # a sequence's cost does not depend on where it sits
+    assert rel_err(got[0], o_last).max() <= TOL_FAST
+    assert rel_err(cum.cpu().numpy()[:base], o_cum).max() <= TOL_FAST
+    assert res.status == 0 and res.best_ordinal == o_best.best_index       # lowest ordinal among 256 exact ties
+    assert res.rollout_steps == n * depth * 20
+    # strict kernel, same launch shape
+    res64 = solver.eval_candidates(p, d_rud, d_thr, n, M.PREC_F64, M.SELECT_LAST_STEP, last, None)
+    assert rel_err(last.cpu().numpy()[:base], o_last).max() <= TOL_F64 and res64.best_ordinal == o_best.best_index
+
+
+def test_negative_or_non_finite_weights_are_rejected(solver):
+    """scores are ordered through their bit patterns, which needs them >= 0: weights outside [0, inf) are an argument
+    error (cfg/mpc.cfg:11-15 allows [0, 10], [0, 60], [0, 10]), not a silently arbitrary winner"""
+    for bad in ((-1.0, 20.0, 5.0), (1.0, float("nan"), 5.0), (1.0, 20.0, float("inf"))):
+        p = _circle_problem(4, W.uniform_substeps())
+        p.w_distance, p.w_heading, p.w_speed = bad
+        with pytest.raises(M.MpcError) as e:
+            solver.eval_seeded(p, W.SEED, 0, 256)
+        assert e.value.status == 1 and "weights" in str(e.value)
+        with pytest.raises(M.MpcError):
+            solver.solve_tree(p, 2)
+    p = _circle_problem(4, W.uniform_substeps())
+    p.w_distance, p.w_heading, p.w_speed = 0.0, 0.0, 0.0                    # zeros are fine: everything ties at 0, ordinal 0 wins
+    assert solver.eval_seeded(p, W.SEED, 0, 256).best_ordinal == 0

@@ -168,6 +168,32 @@ def test_sharded_search_equals_the_whole_search(solver, prec, n_shards, split):
         solver.solve_tree(p, depth, split_level=depth, shard=0, n_shards=2)  # the split level must be a stored level
 
 
+@pytest.mark.parametrize("prec", [M.PREC_F64, M.PREC_FAST])
+@pytest.mark.parametrize("how", ["deadline", "max_nodes"])
+def test_sharded_search_that_ends_at_its_split_level(solver, prec, how):
+    """A shard > 0 whose search stops right after the split level (the clock passes end_time, or the next level's slice
+    is wider than max_nodes) has already sliced that level: its result must still be the WHOLE level's winner -- the
+    trajectory of the unsharded search truncated there -- not the node `shard offset + leaf` of the slice."""
+    p, depth = _semicircle(6.5)
+    depth, split = min(depth, 5), 2
+    want, wl = solver.solve_tree(p, split, precision=prec)                 # the unsharded search, truncated at the split level
+    for shard, n_shards in ((1, 2), (2, 3)):
+        if how == "deadline":
+            calls = [0]
+
+            def now():                       # polled at the top of an iteration and after its level: 2 polls per level
+                calls[0] += 1
+                return 0.0 if calls[0] <= 2 * split else 2.0
+            res, lv = solver.solve_tree(p, depth, precision=prec, now=now, end_time=1.0, split_level=split, shard=shard, n_shards=n_shards)
+        else:                                # level 3 has 3745 leaves: no shard's slice of it fits 1000 nodes
+            res, lv = solver.solve_tree(p, depth, precision=prec, max_nodes=1000, split_level=split, shard=shard, n_shards=n_shards)
+        assert res.status == 0 and res.levels == split
+        assert (res.best_ordinal, res.best_last, res.best_cumulative) == (want.best_ordinal, want.best_last, want.best_cumulative)
+        assert traj_array(res).tobytes() == traj_array(want).tobytes()
+        for l in range(split):
+            assert (lv[l].n_leaves, lv[l].best_leaf, lv[l].best_score) == (wl[l].n_leaves, wl[l].best_leaf, wl[l].best_score)
+
+
 @pytest.mark.parametrize("case", range(8))
 def test_random_tree_problems(solver, case):
     """randomly drawn references, start states, currents, weights, last controls and granularities (fixed seed): the
