@@ -119,6 +119,18 @@ def main():
                     help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: start the N ranks ourselves, BEFORE anything in this process touches the GPU (a
+    # process that has initialised HIP must never be replaced or forked into ranks), and relay rank 0's JSON line
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     # ONE JSON line on stdout: RCCL prints a version banner on file descriptor 1 when the first communicator comes up,
     # so everything but our line is sent to stderr at the descriptor level
     sys.stdout.flush()
@@ -129,7 +141,7 @@ def main():
     import torch.distributed as dist
     import mpc_amd as M
     from mpc_amd import workloads as W
-    from mpc_amd.distributed import ShardCombiner, combine_winners
+    from mpc_amd.distributed import ShardCombiner, combine_winners_exact_device
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +157,13 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # how many ranks RCCL really connected: an all-reduce of ones over the communicator the combine step uses
+    rccl_ranks = None
+    if dist.is_initialized():
+        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == world, (rccl_ranks, world)
 
     prec = M.PREC_FAST if args.precision == "fast" else M.PREC_F64
     stream = torch.cuda.Stream()
@@ -242,9 +261,9 @@ def main():
                     dist.barrier()
                 a = time.perf_counter()
                 solver.eval_candidates(problem, d_rud, d_thr, count, prec, M.SELECT_LAST_STEP, d_last, d_cum)
-                if combine:
+                if combine:             # the synchronous form of the exact cross-shard decision (two 16-byte all-gathers)
                     solver.copy_winners(d_win)
-                    combine_winners(d_win, ordinal_offset=offset, always=args.force_collective)[1].item()
+                    combine_winners_exact_device(solver, d_win, ordinal_stride=count)[0, 1].item()
                 lat.append((time.perf_counter() - a) * 1e3)
             p50 = float(np.median(lat))
 
@@ -258,7 +277,8 @@ def main():
         line = {
             "metric": "candidate_rollout_steps_per_sec",
             "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "ms_per_step": elapsed / args.steps * 1e3, "timed_region_ms": elapsed * 1e3, "rccl_ranks": rccl_ranks,
+            "higher_is_better": True,
             "scaling": "strong" if args.workload == "config5" else "weak",     # config 5 splits a fixed 4096-vessel fleet
             "vs_baseline": None,
             "dtype": "f64",
@@ -267,7 +287,9 @@ def main():
                        "depth": depth, "substeps_per_level": nsub,
                        "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
                        "selection": "last_step",
-                       "parallelism": ("candidate shards; one async RCCL all-gather of the packed winners per %d solves, reduced one batch later" % args.combine_batch if combine else
+                       "parallelism": ("candidate shards; per %d solves one async RCCL all-gather of the packed winners, strict re-score of "
+                                       "cross-shard near-ties (mpc_hip_rescore_tied_shards), second all-gather, combine: the reference's "
+                                       "first strict minimum across GPUs" % args.combine_batch if combine else
                                        ("problem shards, no collective" if world > 1 else "single GPU"))},
             "clock_ramp_s": args.ramp_seconds if args.workload == "config2" else 0.0,
             "p50_solve_latency_ms": p50,
@@ -277,7 +299,8 @@ def main():
             "solve_gpu_ms": total_ms_sum / max(runs, 1),
             "chosen": {"ordinal": int(res.best_ordinal) + offset, "rudder": res.first_rudder,
                        "throttle": res.first_throttle, "last_score": res.best_last,
-                       "global_ordinal_after_combine": (int(combined[1][0].item()) if combined else None)},
+                       "global_ordinal_after_combine": (int(combined[1][0].item()) if combined else None),
+                       "cross_shard_near_tie_rows": (combiner.tied_rows() if combiner else None)},
             "roofline": {
                 "bound": "valu",
                 "bound_note": "FP64 vector ALU (SURVEY.md 8d): neither mfma nor hbm -- sequential per-candidate ODE "

@@ -245,6 +245,22 @@ int         mpc_hip_set_winner_sink(mpc_hip_handle *h, uint64_t *d_dst);
  * (controller.cpp:158-166) across GPUs.  No counterpart in the reference (it has one device: none). */
 int         mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards,
                                    uint32_t n_problems, uint64_t ordinal_stride, uint64_t *d_out);
+/* Stage 1 of the EXACT cross-shard decision for fast-mode runs.  Inside a shard, candidates within MPC_REFINE_REL of
+ * the shard's minimum are already decided by the strict model; ACROSS shards the gathered winners carry fast scores
+ * (~1.2e-7 relative), which cannot order two shards that close.  d_gathered[shard][row][2] is the all-gather of the
+ * copy_winners / winner-sink records (n_rows = solves in the batch x resident problems, row % problems = problem).
+ * For every row in which more than one shard lies within MPC_REFINE_REL of the row's minimum and my_shard is one of
+ * them, this shard's winner is evaluated once more with the strict model -- from the last run's candidate source:
+ * the seed, or the explicit arrays of the last mpc_hip_run_candidates, which must still be valid -- and d_out[row] =
+ * (strict score bits, GLOBAL ordinal); every other row passes through with its ordinal made global (+ my_shard *
+ * ordinal_stride).  After a second all-gather of d_out, mpc_hip_combine_shards(..., ordinal_stride 0, ...) gives the
+ * reference's first strict minimum (controller.cpp:158-166) across GPUs: the true minimum always lies inside the
+ * near set, and every record outside it is larger than every strict score inside it.  Strict-mode runs pass through
+ * unchanged.  One tiny kernel on the handle's stream.  h_tied_rows (optional; synchronises): rows that had a
+ * cross-shard near-tie since the handle was created, as counted by shard 0 (d_gathered == NULL: only read it).
+ * No counterpart in the reference. */
+int         mpc_hip_rescore_tied_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
+                                        uint32_t my_shard, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows);
 /* Which runs carry HIP events: every `period`-th run of the handle (1 = all, the default; 0 = none).  The events
  * ride ON the run's two dispatches (the kernels' own begin/end timestamps), but a dispatch with events still
  * costs ~5 us more than one without, so throughput callers sample (bench.py: every 8th) or switch them off.

@@ -143,7 +143,7 @@ extern "C" void mpc_hip_destroy(mpc_hip_handle *h)
     (void)hipFree(h->d_results); (void)hipHostFree(h->h_results);
     (void)hipFree(h->d_winners); (void)hipFree(h->d_list_count); (void)hipFree(h->d_pcnt); (void)hipFree(h->d_snap);
     (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord); (void)hipFree(h->d_keys);
-    (void)hipFree(h->d_controls); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
+    (void)hipFree(h->d_controls); (void)hipFree(h->d_tied_rows); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
     mpc_tree_free(h);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -381,6 +381,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     h->runs++;
     h->last_count = count; h->last_first = first; h->last_precision = precision; h->last_selection = selection;
     h->last_seeded = seeded; h->ran = true;
+    h->last_rud = d_rud; h->last_thr = d_thr;
     return MPC_OK;
 }
 
@@ -523,6 +524,46 @@ extern "C" int mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathe
     hipLaunchKernelGGL(combine_shards_kernel, dim3((n_problems + 255) / 256), dim3(256), 0, h->stream, d_gathered, n_shards,
                        n_problems, ordinal_stride, d_out);
     HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+extern "C" int mpc_hip_rescore_tied_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
+                                           uint32_t my_shard, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows)
+{
+    if (h && !d_gathered && h_tied_rows) {           /* read the counter only */
+        if (int s = mpc_use_device(h)) return s;
+        *h_tied_rows = 0;
+        if (!h->d_tied_rows) return MPC_OK;
+        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_tied_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(h_tied_rows, h->h_pair, sizeof(uint32_t));
+        return MPC_OK;
+    }
+    if (!h || !d_gathered || !d_out || n_shards == 0 || n_rows == 0 || my_shard >= n_shards) {
+        mpc_set_err("rescore_tied_shards: NULL, empty or out-of-range argument"); return MPC_ERR_INVALID;
+    }
+    if (!h->ran) { mpc_set_err("rescore_tied_shards: nothing has run since the last upload"); return MPC_ERR_INVALID; }
+    if (n_rows % h->n_probs) { mpc_set_err("rescore_tied_shards: n_rows is not a multiple of the resident problems"); return MPC_ERR_INVALID; }
+    if (int s = mpc_use_device(h)) return s;
+    if (!h->d_tied_rows) {
+        HIP_TRY(hipMalloc(&h->d_tied_rows, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(h->d_tied_rows, 0, sizeof(uint32_t), h->stream));
+    }
+    const dim3 grid((n_rows + 63) / 64), blk(64);
+    /* only fast-mode winners need it: strict-mode records already carry the reference's arithmetic (negative: pass through) */
+    const double rel = h->last_precision == MPC_PREC_FAST ? MPC_REFINE_REL : -1.0;
+    if (h->last_seeded)
+        hipLaunchKernelGGL(rescore_tied_kernel<true>, grid, blk, 0, h->stream, h->d_probs, h->n_probs, nullptr, nullptr, h->last_first,
+                           h->last_count, h->last_selection, d_gathered, n_shards, n_rows, my_shard, ordinal_stride, rel, d_out, h->d_tied_rows);
+    else
+        hipLaunchKernelGGL(rescore_tied_kernel<false>, grid, blk, 0, h->stream, h->d_probs, h->n_probs, h->last_rud, h->last_thr, h->last_first,
+                           h->last_count, h->last_selection, d_gathered, n_shards, n_rows, my_shard, ordinal_stride, rel, d_out, h->d_tied_rows);
+    HIP_TRY(hipGetLastError());
+    if (h_tied_rows) {                       /* optional read-back (synchronises): rows with a cross-shard near-tie so far */
+        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_tied_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(h_tied_rows, h->h_pair, sizeof(uint32_t));
+    }
     return MPC_OK;
 }
 

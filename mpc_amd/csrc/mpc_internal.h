@@ -96,6 +96,8 @@ struct mpc_hip_handle {
     double *d_controls = nullptr;                               /* 2 * MPC_MAX_DEPTH, mpc_hip_rollout */
     void *d_static_scratch = nullptr;                           /* this device's copy of scratch[] (mpc_hip.hip), not owned */
 
+    const float *last_rud = nullptr, *last_thr = nullptr;       /* the last run's explicit control arrays (caller memory) */
+    uint32_t *d_tied_rows = nullptr;                            /* counter of mpc_hip_rescore_tied_shards */
     uint64_t last_count = 0, last_first = 0;
     int last_precision = 0, last_selection = 0, last_seeded = 0;
     bool ran = false;

@@ -474,6 +474,50 @@ __global__ __launch_bounds__(256) void combine_shards_kernel(const uint64_t *__r
     out[2 * p] = k; out[2 * p + 1] = o;
 }
 
+/* multi-GPU, fast mode: stage 1 of the EXACT cross-shard decision.  The gathered winners carry fast scores (good to
+ * ~1.2e-7 relative), so two shards whose winners lie within refine_rel of each other cannot be ordered by them.  A lane
+ * per row (solve x problem): where more than one shard lies within refine_rel of the row's minimum and THIS shard is
+ * one of them, its winner is evaluated once more with the strict model (the reference's arithmetic) and (strict score
+ * bits, global ordinal) replaces its record; otherwise the record passes through with its ordinal made global.  After
+ * a second all-gather of these records combine_shards_kernel (stride 0) yields the reference's first strict minimum:
+ * the true minimum is always inside the near set (refine_rel is 9x the fast model's error), and every record outside
+ * it is larger than every strict score inside it.  Rare path: reads the problem from global memory, no staging. */
+template <bool SEEDED>
+__global__ __launch_bounds__(64) void rescore_tied_kernel(const DevProblem *__restrict__ probs, uint32_t n_probs,
+                                                          const float *__restrict__ rud, const float *__restrict__ thr,
+                                                          uint64_t first, uint64_t count, int selection,
+                                                          const uint64_t *__restrict__ gathered, uint32_t n_shards,
+                                                          uint32_t n_rows, uint32_t my_shard, uint64_t ordinal_stride,
+                                                          double refine_rel, uint64_t *__restrict__ out,
+                                                          uint32_t *__restrict__ tied_rows)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    uint64_t kmin = ~0ull;
+    for (uint32_t s = 0; s < n_shards; s++) kmin = min(kmin, gathered[((uint64_t)s * n_rows + row) * 2]);
+    const uint64_t *mine = gathered + ((uint64_t)my_shard * n_rows + row) * 2;
+    uint64_t key = mine[0];
+    const uint64_t reported = mine[1];             /* as K1 numbered it: first + index, the ordinal its controls came from */
+    const uint64_t ordinal = reported == ~0ull ? ~0ull : reported + (uint64_t)my_shard * ordinal_stride;
+    if (refine_rel >= 0.0 && kmin < KEY_INF) {
+        const double m = __longlong_as_double((long long)kmin);
+        const double limit = m + m * refine_rel;
+        uint32_t near = 0;
+        for (uint32_t s = 0; s < n_shards; s++)
+            near += __longlong_as_double((long long)gathered[((uint64_t)s * n_rows + row) * 2]) <= limit;
+        if (near > 1 && my_shard == 0) atomicAdd(tied_rows, 1u);       /* counted once per row, for reporting */
+        if (near > 1 && reported != ~0ull && __longlong_as_double((long long)key) <= limit) {
+            const DevProblem &P = probs[row % n_probs];
+            const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
+            const uint64_t index = SEEDED ? 0 : min(reported - first, count - 1);     /* explicit arrays: this shard's own */
+            double last, cum;
+            eval_strict<SEEDED>(P, P.cp, P.sub, c, reported, index, last, cum, nullptr, snap_none());
+            key = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
+        }
+    }
+    out[2 * (uint64_t)row] = key; out[2 * (uint64_t)row + 1] = ordinal;
+}
+
 /* single explicit control sequence (double precision controls), mpc_hip_rollout */
 __global__ __launch_bounds__(64) void rollout_one_kernel(const DevProblem *__restrict__ probs,
                                                          const double *__restrict__ controls, int precision,

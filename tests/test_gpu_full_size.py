@@ -87,3 +87,106 @@ def test_config5_fleet_batch(solver):
     alone = solver.eval_seeded(probs[1234], seeds[1234], 0, n, M.PREC_FAST)
     assert alone.best_ordinal == res[1234].best_ordinal and alone.best_last == res[1234].best_last
     assert res[0].rollout_steps == n * 20 * 20
+
+
+def test_config4_the_whole_16M_set_as_8_shards_and_as_one_launch():
+    """BASELINE config 4 at its real size: 2^24 device-generated candidates x 30 s x 20 substeps.  The 8 contiguous
+    shards a node's 8 GPUs would hold run one after the other on this GPU (one handle each, as one process per GPU
+    holds one), their packed winners are gathered and combined (a) by mpc_hip_combine_shards on the fast keys and (b)
+    by the exact decision (mpc_hip_rescore_tied_shards -> combine); both must be the winner of ONE 2^24-candidate
+    launch, whose costs the shards reproduce bit for bit, and a strided 1/4096 oracle sample over the whole ordinal
+    range is within 1e-5 and never better than the winner (controller.cpp:158-166: first strict minimum)."""
+    torch = _torch()
+    from mpc_amd.distributed import combine_shards_exact
+    p = W.config2_problem(depth=30)
+    total, world = 1 << 24, 8
+    whole = M.Solver(0)
+    shards = [M.Solver(0) for _ in range(world)]
+    try:
+        last_all = torch.empty(total, dtype=torch.float64, device="cuda")
+        res_all = whole.eval_seeded(p, W.SEED, 0, total, M.PREC_FAST, M.SELECT_LAST_STEP, last_all, None)
+        assert res_all.status == 0 and res_all.evaluated == total and res_all.rollout_steps == total * 30 * 20
+        last_sh = torch.empty(total, dtype=torch.float64, device="cuda")
+        wins = torch.zeros((world, 1, 2), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for s, solver in enumerate(shards):
+            first, count = shard_range(total, s, world)
+            assert count == 1 << 21
+            solver.upload([p], [W.SEED])
+            solver.run_seeded(first, count, M.PREC_FAST, M.SELECT_LAST_STEP, last_sh[first:first + count], None)
+            solver.copy_winners(wins[s])
+            r = solver.fetch()[0]
+            assert r.status == 0 and first <= r.best_ordinal < first + count
+        assert torch.equal(last_sh.view(torch.int64), last_all.view(torch.int64))         # every candidate, bit for bit
+        out_fast = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        shards[0].combine_shards(wins, world, 1, 0, out_fast)
+        shards[0].synchronize()
+        out_exact = combine_shards_exact(shards, wins, 0)
+        best = int(res_all.best_ordinal)
+        assert int(out_fast[0, 1]) == best and int(out_exact[0, 1]) == best
+        key = int(np.float64(res_all.best_last).view(np.int64))
+        assert int(out_fast[0, 0]) == key and int(out_exact[0, 0]) == key
+        # the device argmin is the first minimum of the device costs
+        host = last_all.cpu().numpy()
+        assert best == int(np.argmin(host)) and host[best] == res_all.best_last
+        # oracle: strided sample of the WHOLE range + the winner itself
+        stride = 4096
+        o_last, _, _ = oracle_seeded(p, W.SEED, 0, total // stride, stride=stride)
+        assert rel_err(host[::stride], o_last).max() <= TOL_FAST
+        w_last, _, _ = oracle_seeded(p, W.SEED, best, 1)
+        assert rel_err(res_all.best_last, w_last[0]) <= TOL_FAST and w_last[0] <= o_last.min()
+    finally:
+        whole.close()
+        for s in shards:
+            s.close()
+
+
+def test_cross_shard_near_tie_is_decided_by_the_strict_model():
+    """Two shards whose winners lie within MPC_REFINE_REL of each other and whose FAST scores order them the other way
+    round than the reference's arithmetic does: the fast-key combine picks the wrong shard, the exact decision the
+    right one.  The pair is searched among 2^20 candidates of config 2 (adjacent in strict order, inverted in fast
+    order), then each becomes a one-candidate shard, in both shard orders."""
+    torch = _torch()
+    from mpc_amd.distributed import combine_shards_exact
+    p = W.config2_problem(depth=20)
+    n = 1 << 20
+    s0, s1 = M.Solver(0), M.Solver(0)
+    try:
+        d = torch.empty(n, dtype=torch.float64, device="cuda")
+        s0.eval_seeded(p, W.SEED, 0, n, M.PREC_FAST, M.SELECT_LAST_STEP, d, None)
+        fast = d.cpu().numpy().copy()
+        s0.eval_seeded(p, W.SEED, 0, n, M.PREC_F64, M.SELECT_LAST_STEP, d, None)
+        strict = d.cpu().numpy().copy()
+        order = np.argsort(strict, kind="stable")
+        fs, ss = fast[order], strict[order]
+        flips = np.flatnonzero((ss[1:] > ss[:-1]) & (fs[1:] < fs[:-1]) & np.isfinite(ss[1:]))
+        assert flips.size > 0, "no pair of candidates whose fast scores invert their strict order"
+        a, b = int(order[flips[0]]), int(order[flips[0] + 1])              # strict: a < b; fast: b < a
+        assert strict[a] < strict[b] and fast[b] < fast[a] and fast[a] <= fast[b] * (1 + M.REFINE_REL)
+        ctl = {}
+        for o in (a, b):
+            r, t = W.seeded_controls(W.SEED, o, 1, 20, p.last_rudder, p.last_throttle)
+            ctl[o] = (torch.tensor(r.astype(np.float32), device="cuda").contiguous(),
+                      torch.tensor(t.astype(np.float32), device="cuda").contiguous())
+        for first_shard, second_shard in ((b, a), (a, b)):
+            wins = torch.zeros((2, 1, 2), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            for s, (solver, o) in enumerate(((s0, first_shard), (s1, second_shard))):
+                res = solver.eval_candidates(p, ctl[o][0], ctl[o][1], 1, M.PREC_FAST)
+                assert res.best_ordinal == 0 and res.best_last == fast[o]                # one candidate: local ordinal 0
+                solver.copy_winners(wins[s])
+                solver.synchronize()
+            out_fast = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            s0.combine_shards(wins, 2, 1, 1, out_fast)                                   # ordinal stride 1: global = shard index
+            s0.synchronize()
+            out_exact = combine_shards_exact([s0, s1], wins, 1)
+            shard_of = {first_shard: 0, second_shard: 1}
+            assert int(out_fast[0, 1]) == shard_of[b]                                    # the fast keys prefer b ...
+            assert int(out_exact[0, 1]) == shard_of[a]                                   # ... the reference's arithmetic a
+            assert int(out_exact[0, 0]) == int(np.float64(strict[a]).view(np.int64))
+        assert s0.rescore_tied_shards(None, 0, 0, 0, 0, None, read_count=True) == 2      # both rounds had a near-tie row
+    finally:
+        s0.close()
+        s1.close()

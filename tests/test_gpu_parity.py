@@ -269,3 +269,39 @@ def test_timing_period_samples_runs_and_changes_no_result(solver):
         assert solver.timing(reset=True)[0] == 0
     finally:
         solver.set_timing(1)
+
+
+def test_shard_combiner_exact_pipeline_one_rank_rccl():
+    """The staged pipeline bench.py --gpus N runs (all-gather -> strict re-score of near-tied shards -> all-gather ->
+    combine), rehearsed over RCCL with a one-rank group on this GPU: every solve's combined winner is its own winner,
+    through full batches, a partial one and slot wrap-around; a lone shard never ties."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from mpc_amd.distributed import ShardCombiner, bits_to_score
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    stream = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(stream):
+            solver = M.Solver(0, stream=stream.cuda_stream)          # collectives and kernels ordered on one stream
+            p = W.config2_problem(depth=5)
+            comb = ShardCombiner(solver, 1, ordinal_stride=0, batch=3, slots=3, always=True, exact=True)
+            assert comb.exact and comb.collective
+            seen = []
+            for k in range(11):                                      # 3 full batches + a partial one: slots wrap
+                solver.upload([p], [200 + k])
+                comb.begin()
+                solver.run_seeded(0, 2048, M.PREC_FAST)
+                comb.submit()
+                seen.append(solver.fetch()[0])
+            key, ordinal = comb.flush()
+            assert int(ordinal[0].item()) == seen[-1].best_ordinal and bits_to_score(key)[0] == seen[-1].best_last
+            assert comb.results.view(comb.B, 1, 2)[:2, 0, 1].cpu().tolist() == [r.best_ordinal for r in seen[9:11]]
+            assert comb.tied_rows() == 0
+            solver.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
