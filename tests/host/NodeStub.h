@@ -24,15 +24,21 @@ public:
     {
         std::lock_guard<std::mutex> lock(m_Mutex);
         lastTrajectory = trajectory;
+        if (displayed == 0) firstTrajectory = trajectory;
         displayed++;
-        (void)plannerTrajectory; (void)achievable;
+        lastAchievable = achievable;
+        (void)plannerTrajectory;
     }
     void timedOut() override { std::lock_guard<std::mutex> lock(m_Mutex); timedOutCalls++; }
     double getTime() const override { return m_Frozen ? m_Time : Controller::getTime(); }
 
     std::vector<std::pair<double, double>> controls;
-    std::vector<State> lastTrajectory;
+    std::vector<State> lastTrajectory, firstTrajectory;
     int displayed = 0, timedOutCalls = 0;
+    bool lastAchievable = true;            /* the m_Achievable the controller passed to its latest displayTrajectory */
+    std::vector<std::pair<double, double>> controlsNow() { std::lock_guard<std::mutex> lock(m_Mutex); return controls; }
+    int displayedNow() { std::lock_guard<std::mutex> lock(m_Mutex); return displayed; }
+    bool achievableNow() { std::lock_guard<std::mutex> lock(m_Mutex); return lastAchievable; }
 
 private:
     bool m_Frozen;

@@ -209,6 +209,65 @@ static void mpcErrorBehaviour()
     CHECK(threw);
 }
 
+/* The achievability block of updateReferenceTrajectory (controller.cpp:312-335) and getStateAfterCurrentControl's
+ * discarded simulate (:345-359), pinned against the oracle with a frozen clock:
+ *   score <= threshold  -> the state ON the plan at the predicted state's time, m_Achievable = true
+ *   otherwise           -> the predicted state with heading = course made good and speed = speed over ground,
+ *                          m_Achievable = (threshold == 0)
+ * m_Achievable is observable through the `achievable` argument of the displayTrajectory calls that follow. */
+static void achievabilityBlock(double threshold)
+{
+    const double cx = 0.2, cy = -0.1, planSeconds = 4.5;
+    NodeStub stub(true, 1000.0);
+    Controller c(&stub);
+    c.updateConfig(0.0625, 0.125, 1, 20, 5, threshold, true, 5);
+    c.updateDisturbanceEstimate(cx, cy);
+    const State where(0, 0, 0, 2.5, 4);
+    c.updatePosition(where);
+    DubinsPlan plan = semicircle(nullptr, planSeconds);
+    const State got = c.updateReferenceTrajectory(plan, 11, true);
+
+    /* the oracle, from the UN-ADVANCED position: getStateAfterCurrentControl discards what it simulates (:357) */
+    orc_config cfg; orc_default_config(&cfg); cfg.current_x = cx; cfg.current_y = cy;
+    const double qi[3] = {0, 0, M_PI / 2}, param[3] = {0, M_PI, 0};
+    orc_dubins od; orc_dubins_fill(&od, qi, param, 8, ORC_LRL, 2.5, 4); od.end_time = 4 + planSeconds;
+    const int mi = orc_max_iterations(&od, 1, 4.0);
+    orc_state cps[16];
+    for (int i = 0; i < mi; i++) { cps[i].time = 4.0 + (i + 1); orc_plan_sample(&od, 1, &cps[i]); }
+    orc_mpc_state traj[17]; orc_level_result lv[16]; uint64_t nodes;
+    const int it = orc_mpc_tree(&cfg, to_orc(where), cps, mi, -1, traj, lv, &nodes);
+    CHECK(it == mi && mi == 3);
+    orc_state onPlan{0, 0, 0, 0, traj[1].v.s.time};
+    orc_plan_sample(&od, 1, &onPlan);
+    const double score = orc_compare_states(&onPlan, &traj[1].v, 1, 20, 5);
+    CHECK(score > 1.0 && score < 20.0);                  /* both thresholds below are on the side they are meant to be */
+
+    /* the first solve started from the position as given, not 0.1 s further along */
+    CHECK(stub.firstTrajectory.size() == (size_t)it + 1);
+    CHECK(stub.firstTrajectory[0].x() == where.x() && stub.firstTrajectory[0].y() == where.y());
+    CHECK(stub.firstTrajectory[0].heading() == where.heading() && stub.firstTrajectory[0].time() == where.time());
+    const auto issued = stub.controlsNow();                   /* the MPC thread keeps appending */
+    CHECK(issued.size() >= 1 && issued[0].first == traj[1].last_rudder && issued[0].second == traj[1].last_throttle);
+
+    CHECK(got.time() == traj[1].v.s.time);
+    if (score <= threshold) {
+        CHECK(got.x() == onPlan.x && got.y() == onPlan.y && got.heading() == onPlan.heading && got.speed() == onPlan.speed);
+    } else {
+        CHECK(std::fabs(got.x() - traj[1].v.s.x) <= 1e-12 && std::fabs(got.y() - traj[1].v.s.y) <= 1e-12);
+        CHECK(std::fabs(got.heading() - traj[1].v.cmg) <= 1e-12);            /* heading := course made good */
+        CHECK(std::fabs(got.speed() - traj[1].v.sog) <= 1e-12);              /* speed := speed over ground */
+        CHECK(std::fabs(got.heading() - traj[1].v.s.heading) > 1e-3);        /* ... which differ from the state's own under a current */
+    }
+    /* m_Achievable as the MPC thread's next displayTrajectory reports it */
+    const int before = stub.displayedNow();
+    for (int i = 0; i < 200 && stub.displayedNow() < before + 2; i++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    CHECK(stub.displayedNow() >= before + 2);
+    const bool want = score <= threshold ? true : threshold == 0;
+    CHECK(stub.achievableNow() == want);
+    c.terminate();
+    std::this_thread::sleep_for(std::chrono::milliseconds(200));
+}
+
 /* ControllerTests.updateReferenceTrajectoryTest (test_controller.cpp:449-479), shortened: real clock, the MPC thread
  * issues controls at its own pace while positions are fed along the plan; no numeric assertion in the reference. */
 static void updateReferenceTrajectoryTest()
@@ -252,6 +311,9 @@ int main(int argc, char** argv)
         mpcMatchesOracle(5.5, 0.2, -0.1);
         mpcMatchesOracle(6.5, 0.0, 0.0);
         mpcErrorBehaviour();
+        achievabilityBlock(20.0);                 /* cfg default (mpc.cfg:17-18): achievable -> the state on the plan */
+        achievabilityBlock(1e-9);                 /* not achievable -> predicted state, m_Achievable false */
+        achievabilityBlock(0.0);                  /* threshold 0: always the prediction, never reported as failure */
         updateReferenceTrajectoryTest();
     }
     std::printf("%s: %d checks, %d failed\n", gpu ? "gpu" : "cpu", g_checks, g_failed);
