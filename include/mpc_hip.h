@@ -110,7 +110,6 @@ typedef struct {
     mpc_level_state trajectory[MPC_MAX_DEPTH + 1];   /* [levels+1]; [0] = start (controller.cpp:185-188)      */
 } mpc_result;
 
-typedef struct mpc_hip_handle mpc_hip_handle;
 
 /* ---- library ------------------------------------------------------------------------------------------ */
 int         mpc_hip_abi_version(void);
@@ -123,6 +122,29 @@ void        mpc_hip_default_problem(mpc_problem *p);
 /* VehicleState.h:49-53: the substep lengths simulate() uses for duration t, written to out[cap].
  * Returns the count (11 for t = 1.0: ten of 0.1 and one of 1.39e-16). */
 int         mpc_hip_substep_schedule(double t, double *out, int cap);
+
+typedef struct mpc_hip_handle mpc_hip_handle;
+
+/* The boat: the 11 model parameters of VehicleState.h:86-96 (compile-time constants in the reference, with the note
+ * "should allow setting of boat characteristics", :84).  What estimate() derives from them (:98-101: max prop speed,
+ * max force, prop and drag coefficients) is computed by the library. */
+typedef struct {
+    double idle_rpm, max_rpm, max_rpm_change_rate;          /* VehicleState.h:86-88 */
+    double prop_ratio, prop_pitch;                          /* :89-90 */
+    double max_rudder_angle, rudder_coefficient, rudder_distance;   /* :91-93 (radians; the reference: pi/6) */
+    double mass, max_power, max_speed;                      /* :94-96 */
+} mpc_model;
+/* the reference's own values */
+void        mpc_hip_default_model(mpc_model *m);
+/* Replaces the compile-time constants of VehicleState.h:86-96 for this handle: problem p of every later upload /
+ * solve / fleet current estimate uses models[p % n_models] (n_models == 1: one hull for everything; n_models == the
+ * fleet's size: a hull per vessel).  A new handle holds the reference's hull, with which every result is bit for bit
+ * what it was before this call existed.  Resident problems are dropped (upload again).  Parameters must be finite,
+ * max_rpm > idle_rpm, and change rate, prop ratio and pitch, rudder distance, mass, power and speed positive
+ * (MPC_ERR_INVALID otherwise).  MPC_PREC_F64 takes any such hull.  MPC_PREC_FAST additionally needs what its
+ * approximations assume -- max_rudder_angle <= pi/4 and at most 0.06 rad of yaw per 0.1-s substep (the reference's
+ * hull: 0.049) -- and runs with a hull outside that fail with MPC_ERR_INVALID naming MPC_PREC_F64. */
+int         mpc_hip_set_model(mpc_hip_handle *h, const mpc_model *models, uint32_t n_models);
 
 /* Create a handle on HIP device `device`.  stream: a hipStream_t to launch on, or NULL for a stream the
  * handle creates.  Replaces nothing in the reference (it has no device). */

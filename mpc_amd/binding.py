@@ -20,7 +20,7 @@ REFINE_REL = 1.0e-6
 # every symbol include/mpc_hip.h declares (tests/test_abi.py checks the built library exports them all)
 EXPORTED_SYMBOLS = (
     "mpc_hip_abi_version", "mpc_hip_status_string", "mpc_hip_last_error", "mpc_hip_default_problem",
-    "mpc_hip_substep_schedule", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
+    "mpc_hip_substep_schedule", "mpc_hip_default_model", "mpc_hip_set_model", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
     "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_run_seeded", "mpc_hip_run_seeded_static", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
     "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_rescore_tied_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
@@ -51,6 +51,13 @@ class Problem(C.Structure):
         "min_throttle", "max_throttle", "tolerance")] + [
         ("depth", C.c_int32), ("n_substeps", C.c_int32),
         ("checkpoints", Checkpoint * MAX_DEPTH), ("substeps", C.c_double * MAX_SUBSTEPS)]
+
+
+class Model(C.Structure):
+    """mpc_model: the 11 boat parameters of VehicleState.h:86-96"""
+    _fields_ = [(n, C.c_double) for n in (
+        "idle_rpm", "max_rpm", "max_rpm_change_rate", "prop_ratio", "prop_pitch", "max_rudder_angle",
+        "rudder_coefficient", "rudder_distance", "mass", "max_power", "max_speed")]
 
 
 class Result(C.Structure):
@@ -117,6 +124,8 @@ def load_library(path=None):
     L.mpc_hip_last_error.restype = C.c_char_p
     L.mpc_hip_default_problem.argtypes = [PP]; L.mpc_hip_default_problem.restype = None
     L.mpc_hip_substep_schedule.argtypes = [C.c_double, dp, i32]; L.mpc_hip_substep_schedule.restype = i32
+    L.mpc_hip_default_model.argtypes = [C.POINTER(Model)]; L.mpc_hip_default_model.restype = None
+    L.mpc_hip_set_model.argtypes = [vp, C.POINTER(Model), C.c_uint32]
     L.mpc_hip_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.mpc_hip_destroy.argtypes = [vp]; L.mpc_hip_destroy.restype = None
     L.mpc_hip_synchronize.argtypes = [vp]
@@ -168,6 +177,17 @@ def default_problem():
     p = Problem()
     load_library().mpc_hip_default_problem(C.byref(p))
     return p
+
+
+def default_model(**kw):
+    """the reference's hull (VehicleState.h:86-96), with any of the 11 parameters replaced by keyword"""
+    m = Model()
+    load_library().mpc_hip_default_model(C.byref(m))
+    for k, v in kw.items():
+        if not hasattr(m, k):
+            raise AttributeError(k)
+        setattr(m, k, float(v))
+    return m
 
 
 def substep_schedule(t, cap=4096):
@@ -227,6 +247,13 @@ class Solver:
 
     def synchronize(self):
         _check(self._L.mpc_hip_synchronize(self._h))
+
+    def set_model(self, models):
+        """mpc_hip_set_model: one Model (every problem) or a list (problem p uses models[p % len])"""
+        ms = list(models) if isinstance(models, (list, tuple)) else [models]
+        arr = (Model * len(ms))(*ms)
+        _check(self._L.mpc_hip_set_model(self._h, arr, len(ms)))
+        self._n_problems = 0
 
     # ---- one-call forms ------------------------------------------------------------------------------
     def eval_candidates(self, problem, d_rudders, d_throttles, n, precision=PREC_FAST,

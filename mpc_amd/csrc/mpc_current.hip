@@ -22,12 +22,12 @@ using namespace mpc;
 struct Reckoned { Veh s; double time; };
 
 /* VehicleState::simulate(rudder, throttle, t) with no current (VehicleState.h:43-55) */
-__device__ static inline void reckon(Reckoned &e, double rudder, double throttle, double t)
+__device__ static inline void reckon(Reckoned &e, double rudder, double throttle, double t, const Model &M)
 {
     while (t > 0) {
         const double d = t < 0.1 ? t : 0.1;
         t -= 0.1;
-        strict_level<0>(e.s, rudder, throttle, &d, 1, 0.0, 0.0);            /* a bare dt, not a schedule row */
+        strict_level<0>(e.s, rudder, throttle, &d, 1, 0.0, 0.0, M);           /* a bare dt, not a schedule row */
         e.time += d;
     }
 }
@@ -35,25 +35,27 @@ __device__ static inline void reckon(Reckoned &e, double rudder, double throttle
 __global__ __launch_bounds__(64) void estimate_currents_kernel(const mpc_history_sample *__restrict__ samples,
                                                                const uint32_t *__restrict__ counts, uint32_t stride,
                                                                const double *__restrict__ actual, uint32_t n,
-                                                               double *__restrict__ currents, DevProblem *__restrict__ probs)
+                                                               double *__restrict__ currents, DevProblem *__restrict__ probs,
+                                                               const Model *__restrict__ models, uint32_t n_models)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    const Model M = models[p % n_models];            /* vessel p's hull (mpc_hip_set_model) */
     const mpc_history_sample *hist = samples + (size_t)p * stride;
     const int cnt = (int)counts[p];
     const double ax = actual[3 * p], ay = actual[3 * p + 1], at = actual[3 * p + 2];
     double cx = 0.0, cy = 0.0;
     if (cnt >= MPC_CURRENT_MIN_SAMPLES) {                                                   /* :18 */
-        Reckoned e{Veh{hist[0].x, hist[0].y, hist[0].heading, hist[0].speed, rpm_from_speed(hist[0].speed), 0.0, 0.0},
+        Reckoned e{Veh{hist[0].x, hist[0].y, hist[0].heading, hist[0].speed, rpm_from_speed(hist[0].speed, M), 0.0, 0.0},
                    hist[0].time};                                                           /* :19 */
         const double span = at - e.time;
         if (span > 0) {                                                                     /* :21 */
             for (int i = 0; i < cnt; i++) {                                                 /* :22 */
                 const mpc_history_sample s = hist[i];
-                if (s.time >= at) { reckon(e, s.rudder, s.throttle, at - e.time); break; }  /* :23-27 */
-                reckon(e, s.rudder, s.throttle, s.time - e.time);                           /* :30 */
+                if (s.time >= at) { reckon(e, s.rudder, s.throttle, at - e.time, M); break; }  /* :23-27 */
+                reckon(e, s.rudder, s.throttle, s.time - e.time, M);                          /* :30 */
             }
-            if (e.time < at) reckon(e, hist[cnt - 1].rudder, hist[cnt - 1].throttle, at - e.time);   /* :34-37 */
+            if (e.time < at) reckon(e, hist[cnt - 1].rudder, hist[cnt - 1].throttle, at - e.time, M);   /* :34-37 */
             cx = (ax - e.s.x) / span;                                                       /* :39-40 */
             cy = (ay - e.s.y) / span;
         }
@@ -117,7 +119,7 @@ extern "C" int mpc_hip_estimate_currents(mpc_hip_handle *h, const mpc_history_sa
     HIP_TRY(hipMemcpyAsync(d_counts, h_counts, sizeof(uint32_t) * n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_actual, h_actual, b_actual, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(estimate_currents_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, d_samples, d_counts, stride,
-                       d_actual, n, d_out, apply ? h->d_probs : (DevProblem *)nullptr);
+                       d_actual, n, d_out, apply ? h->d_probs : (DevProblem *)nullptr, h->d_models, (uint32_t)h->models.size());
     HIP_TRY(hipGetLastError());
     if (h_currents_out) HIP_TRY(hipMemcpyAsync(h_currents_out, d_out, b_out, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));      /* the host arrays are the caller's again; the estimates are in place */

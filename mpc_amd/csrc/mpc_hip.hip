@@ -127,6 +127,11 @@ extern "C" int mpc_hip_create(int device, void *stream, mpc_hip_handle **out)
         HIP_TRY(hipMalloc(&h->d_controls, sizeof(double) * 2 * MPC_MAX_DEPTH));
         HIP_TRY(hipHostMalloc(&h->h_pair, sizeof(uint64_t) * 8));
         if (int s2 = static_scratch_ptr(device, &h->d_static_scratch)) return s2;
+        h->models.assign(1, default_model());              /* the reference's hull until mpc_hip_set_model */
+        h->models_fast_ok.assign(1, 1);
+        HIP_TRY(hipMalloc(&h->d_models, sizeof(Model)));
+        h->cap_models = 1;
+        HIP_TRY(hipMemcpy(h->d_models, h->models.data(), sizeof(Model), hipMemcpyHostToDevice));
         return MPC_OK;
     }();
     if (s != MPC_OK) { mpc_hip_destroy(h); return s; }       /* nothing of a half-built handle leaks */
@@ -143,7 +148,7 @@ extern "C" void mpc_hip_destroy(mpc_hip_handle *h)
     (void)hipFree(h->d_results); (void)hipHostFree(h->h_results);
     (void)hipFree(h->d_winners); (void)hipFree(h->d_list_count); (void)hipFree(h->d_pcnt); (void)hipFree(h->d_snap);
     (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord); (void)hipFree(h->d_keys);
-    (void)hipFree(h->d_controls); (void)hipFree(h->d_tied_rows); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
+    (void)hipFree(h->d_controls); (void)hipFree(h->d_models); (void)hipFree(h->d_tied_rows); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
     mpc_tree_free(h);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -209,10 +214,81 @@ int mpc_check_problem(const mpc_problem *p, int precision)
     return MPC_OK;
 }
 
-void mpc_pack_problem(const mpc_problem *p, uint64_t seed, DevProblem *d)
+const Model &mpc_model_of(const mpc_hip_handle *h, uint32_t problem) { return h->models[problem % h->models.size()]; }
+
+/* What the FAST model's approximations assume of a hull (the strict model takes any): rudder angles small enough for
+ * its unreduced sin/cos polynomials (<= pi/4: truncation 2e-14), a yaw of at most 0.06 rad per 0.1-s substep for its
+ * small-angle rotation (the reference's hull: 0.049), and a positive prop speed per rpm (reciprocal square root). */
+static bool model_fits_fast(const Model &m)
 {
+    const double top = fmax(sqrt(fmax((m.max_rpm * m.prop_ratio) / m.prop_pitch, 0.0)), 1.5 * m.max_speed);
+    const double yaw = fabs(m.kyaw) * sin(fmin(fabs(m.max_rudder_angle), PI_2)) * top * 0.1;
+    return fabs(m.max_rudder_angle) <= PI / 4 && yaw <= 0.06 && m.c_prop > 0 && m.idle_rpm >= 0 && m.rpm_span > 0;
+}
+
+int mpc_check_fast_model(const mpc_hip_handle *h, uint32_t n_problems)
+{
+    const uint32_t n = (uint32_t)std::min<size_t>(h->models.size(), n_problems);
+    for (uint32_t i = 0; i < n; i++)
+        if (!h->models_fast_ok[i]) {
+            mpc_set_err("MPC_PREC_FAST does not cover this hull (rudder angle > pi/4 or yaw > 0.06 rad per substep); use MPC_PREC_F64");
+            return MPC_ERR_INVALID;
+        }
+    return MPC_OK;
+}
+
+extern "C" void mpc_hip_default_model(mpc_model *m)
+{
+    if (!m) return;
+    const Model d = default_model();
+    m->idle_rpm = d.idle_rpm; m->max_rpm = d.max_rpm; m->max_rpm_change_rate = d.max_rpm_change_rate;
+    m->prop_ratio = d.prop_ratio; m->prop_pitch = d.prop_pitch; m->max_rudder_angle = d.max_rudder_angle;
+    m->rudder_coefficient = d.rudder_coefficient; m->rudder_distance = d.rudder_distance; m->mass = d.mass;
+    m->max_power = d.max_power; m->max_speed = d.max_speed;
+}
+
+extern "C" int mpc_hip_set_model(mpc_hip_handle *h, const mpc_model *models, uint32_t n_models)
+{
+    if (!h || !models || n_models == 0) { mpc_set_err("set_model: NULL handle/models or zero models"); return MPC_ERR_INVALID; }
+    std::vector<Model> packed(n_models);
+    std::vector<uint8_t> ok(n_models);
+    for (uint32_t i = 0; i < n_models; i++) {
+        const mpc_model &m = models[i];
+        const double v[11] = {m.idle_rpm, m.max_rpm, m.max_rpm_change_rate, m.prop_ratio, m.prop_pitch, m.max_rudder_angle,
+                              m.rudder_coefficient, m.rudder_distance, m.mass, m.max_power, m.max_speed};
+        for (double x : v) if (!isfinite(x)) { mpc_set_err("set_model: parameters must be finite"); return MPC_ERR_INVALID; }
+        if (!(m.max_rpm > m.idle_rpm) || !(m.max_rpm_change_rate > 0) || !(m.prop_pitch > 0) || !(m.rudder_distance > 0) ||
+            !(m.mass > 0) || !(m.max_speed > 0) || !(m.prop_ratio > 0) || !(m.max_power > 0)) {
+            mpc_set_err("set_model: max_rpm > idle_rpm and positive change rate, prop ratio/pitch, rudder distance, mass, power, speed are required");
+            return MPC_ERR_INVALID;
+        }
+        packed[i] = make_model(m.idle_rpm, m.max_rpm, m.max_rpm_change_rate, m.prop_ratio, m.prop_pitch, m.max_rudder_angle,
+                               m.rudder_coefficient, m.rudder_distance, m.mass, m.max_power, m.max_speed);
+        if (!isfinite(packed[i].prop_coefficient) || !isfinite(packed[i].drag_coefficient)) {
+            mpc_set_err("set_model: max prop speed equals max speed (VehicleState.h:100 divides by their squares' difference)");
+            return MPC_ERR_INVALID;
+        }
+        ok[i] = model_fits_fast(packed[i]);
+    }
+    if (int s = mpc_use_device(h)) return s;
+    if (n_models > h->cap_models) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_models); h->d_models = nullptr; h->cap_models = 0;
+        HIP_TRY(hipMalloc(&h->d_models, sizeof(Model) * n_models));
+        h->cap_models = n_models;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));              /* runs in flight read the old device copy */
+    HIP_TRY(hipMemcpy(h->d_models, packed.data(), sizeof(Model) * n_models, hipMemcpyHostToDevice));
+    h->models.swap(packed); h->models_fast_ok.swap(ok);
+    h->n_probs = 0; h->ran = false;                        /* resident problems carry the old hull: upload again */
+    return MPC_OK;
+}
+
+void mpc_pack_problem(const mpc_problem *p, uint64_t seed, const Model &model, DevProblem *d)
+{
+    d->model = model;
     d->sx = p->start_x; d->sy = p->start_y; d->sh = p->start_heading; d->sv = p->start_speed;
-    d->srpm = rpm_from_speed(p->start_speed);
+    d->srpm = rpm_from_speed(p->start_speed, model);
     d->last_r = p->last_rudder; d->last_t = p->last_throttle;
     d->cx = p->current_x; d->cy = p->current_y;
     d->wd = p->w_distance; d->wh = p->w_heading; d->ws = p->w_speed;
@@ -235,7 +311,7 @@ void mpc_pack_problem(const mpc_problem *p, uint64_t seed, DevProblem *d)
     for (int s = 0; s < p->n_substeps; s++) {
         double *q = d->sub + s * SUB_STRIDE;
         const double dt = p->substeps[s];
-        q[0] = dt; q[1] = MAX_RPM_CHANGE_RATE * dt; q[2] = dt / MASS;
+        q[0] = dt; q[1] = model.max_rpm_change_rate * dt; q[2] = dt / model.mass;
         q[3] = p->current_x * dt; q[4] = p->current_y * dt; q[5] = 1.0 / dt;
     }
 }
@@ -252,7 +328,7 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
     HIP_TRY(hipStreamSynchronize(h->stream));     /* the pinned staging buffer may still be in flight */
     h->depth.resize(n_problems); h->nsub.resize(n_problems);
     for (uint32_t p = 0; p < n_problems; p++) {
-        mpc_pack_problem(&h_problems[p], h_seeds ? h_seeds[p] : 0, &h->h_probs[p]);
+        mpc_pack_problem(&h_problems[p], h_seeds ? h_seeds[p] : 0, mpc_model_of(h, p), &h->h_probs[p]);
         h->depth[p] = h_problems[p].depth; h->nsub[p] = h_problems[p].n_substeps;
     }
     HIP_TRY(hipMemcpyAsync(h->d_probs, h->h_probs, sizeof(DevProblem) * n_problems, hipMemcpyHostToDevice, h->stream));
@@ -290,6 +366,8 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     if (!seeded && h->n_probs != 1) { mpc_set_err("explicit control arrays take exactly one problem"); return MPC_ERR_INVALID; }
     if (count > (1ull << 40)) { mpc_set_err("candidate count too large"); return MPC_ERR_TOO_LARGE; }
     if (int s = mpc_use_device(h)) return s;
+    if (precision == MPC_PREC_FAST)
+        if (int s = mpc_check_fast_model(h, h->n_probs)) return s;
     if (precision == MPC_PREC_FAST)
         for (uint32_t p = 0; p < h->n_probs; p++)
             for (int s = 0; s < h->nsub[p]; s++)
@@ -626,6 +704,7 @@ extern "C" int mpc_hip_rollout(mpc_hip_handle *h, const mpc_problem *h_problem, 
     if (!h || !h_problem || !h_rudders || !h_throttles || !h_result) { mpc_set_err("rollout: NULL argument"); return MPC_ERR_INVALID; }
     if (precision != MPC_PREC_FAST && precision != MPC_PREC_F64) { mpc_set_err("unknown precision"); return MPC_ERR_INVALID; }
     if (int s = mpc_check_problem(h_problem, precision)) return s;
+    if (precision == MPC_PREC_FAST) if (int s = mpc_check_fast_model(h, 1)) return s;
     if (int s = mpc_hip_upload_problems(h, h_problem, nullptr, 1)) return s;
     double ctl[2 * MPC_MAX_DEPTH] = {0};
     for (int l = 0; l < h_problem->depth; l++) { ctl[l] = h_rudders[l]; ctl[MPC_MAX_DEPTH + l] = h_throttles[l]; }

@@ -27,6 +27,7 @@ struct DevProblem {
     int32_t depth, nsub;
     int32_t head_uniform;        /* substeps 0 .. nsub-2 equally long (nsub >= 2): every schedule simulate() itself makes */
     int32_t pad0; double pad1;   /* keeps cp 16-byte aligned for the staging vectors */
+    mpc::Model model;            /* this problem's hull (mpc_hip_set_model; VehicleState.h:86-101) */
     double cp[MPC_MAX_DEPTH * CP_STRIDE];
     double sub[MPC_MAX_SUBSTEPS * SUB_STRIDE];
 };
@@ -103,6 +104,9 @@ struct mpc_hip_handle {
     bool ran = false;
     std::vector<int32_t> depth, nsub;
 
+    std::vector<mpc::Model> models;                              /* mpc_hip_set_model: problem p uses models[p % size] */
+    std::vector<uint8_t> models_fast_ok;                         /* ... and whether the fast model's envelope covers it */
+    mpc::Model *d_models = nullptr; size_t cap_models = 0;       /* device copy (fleet current estimation) */
     void *d_plans = nullptr; size_t cap_plans = 0;              /* mpc_plan[P] + start times (mpc_plan.hip) */
     void *d_hist = nullptr; size_t cap_hist = 0;                /* histories, counts, query states, estimates (mpc_current.hip) */
 
@@ -119,7 +123,9 @@ int mpc_use_device(const mpc_hip_handle *h);
 int mpc_ensure_problem_capacity(mpc_hip_handle *h, uint32_t n);
 int mpc_ensure_partials(mpc_hip_handle *h, size_t n);
 int mpc_check_problem(const mpc_problem *p, int precision);
-void mpc_pack_problem(const mpc_problem *p, uint64_t seed, DevProblem *d);
+void mpc_pack_problem(const mpc_problem *p, uint64_t seed, const mpc::Model &model, DevProblem *d);
+const mpc::Model &mpc_model_of(const mpc_hip_handle *h, uint32_t problem);
+int mpc_check_fast_model(const mpc_hip_handle *h, uint32_t n_problems);
 void mpc_tree_free(mpc_hip_handle *h);
 
 /* ---- device helpers ----------------------------------------------------------------------------------------- */

@@ -148,14 +148,15 @@ __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const
 {
     Veh s{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
     const Weights w{P.wd, P.wh, P.ws};
+    const Model M = P.model;                  /* wave-uniform: lives in scalar registers for the whole rollout */
     const double row0[1] = {subL[0]};
     last = 0.0; cum = 0.0;
     if (traj) traj[0] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l < P.depth; l++) {
         double r, t;
         fetch_control<SEEDED, STAGED>(c, ordinal, index, l, r, t);
-        if (UNIFORM) strict_level<0>(s, r, t, row0, P.nsub, P.cx, P.cy);
-        else strict_level<SUB_STRIDE>(s, r, t, subL, P.nsub, P.cx, P.cy);
+        if (UNIFORM) strict_level<0>(s, r, t, row0, P.nsub, P.cx, P.cy, M);
+        else strict_level<SUB_STRIDE>(s, r, t, subL, P.nsub, P.cx, P.cy, M);
         last = strict_score(cpL + l * CP_STRIDE, s, w);
         cum += last;
         if (traj)
@@ -191,6 +192,7 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
     s.x = P.sx; s.y = P.sy; s.v = P.sv; s.rpm = P.srpm; s.delta = 0;
     sincos(P.sh, &s.sh, &s.ch);
     const Weights w{P.wd, P.wh, P.ws};
+    const Model M = P.model;                  /* wave-uniform: scalar registers */
     const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
     const double row0[6] = {subL[0], subL[1], subL[2], subL[3], subL[4], subL[5]};
     last = 0.0; cum = 0.0;
@@ -207,9 +209,9 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
         cp[3] = cpv[3]; cp[4] = cpv[4]; cp[5] = cpv[5]; cp[6] = cpv[6]; cp[7] = cpv[7];
         /* not the LEAN spellings (mpc_model.h): a candidate's cost must not depend on how its set was supplied or
          * sized, and config 2 -- one wave per SIMD -- is 0.6 us faster without them */
-        if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub);
-        else if (P.head_uniform) fast_level_head_uniform(s, r, t, subL, P.nsub);
-        else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub);
+        if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub, M);
+        else if (P.head_uniform) fast_level_head_uniform(s, r, t, subL, P.nsub, M);
+        else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub, M);
         last = fast_score(cp, s, w, q_last);
         cum += last;
         if (traj)
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(64) void rollout_one_kernel(const DevProblem *__res
         Veh s{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
         for (int l = 0; l < P.depth; l++) {
             const double r = controls[l], t = controls[MPC_MAX_DEPTH + l];
-            strict_level(s, r, t, subL, P.nsub, P.cx, P.cy);
+            strict_level(s, r, t, subL, P.nsub, P.cx, P.cy, P.model);
             last = strict_score(cpL + l * CP_STRIDE, s, w);
             cum += last;
             R.traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog,
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(64) void rollout_one_kernel(const DevProblem *__res
         const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
         for (int l = 0; l < P.depth; l++) {
             const double r = controls[l], t = controls[MPC_MAX_DEPTH + l];
-            fast_level(s, r, t, subL, P.nsub);
+            fast_level(s, r, t, subL, P.nsub, P.model);
             last = fast_score(cpL + l * CP_STRIDE, s, w, q_last);
             cum += last;
             R.traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta,

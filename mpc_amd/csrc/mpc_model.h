@@ -40,26 +40,51 @@
 
 namespace mpc {
 
-/* model constants, VehicleState.h:86-101 */
-constexpr double IDLE_RPM = 0.0;
-constexpr double MAX_RPM = 3200.0;
-constexpr double MAX_RPM_CHANGE_RATE = 1000.0;
-constexpr double PROP_RATIO = 0.389105058;
-constexpr double PROP_PITCH = 20.0;
 constexpr double PI = 3.14159265358979323846;
 constexpr double PI_2 = 1.57079632679489661923;
 constexpr double TWO_PI = PI * 2;
 constexpr double THREE_PI = 3 * PI;
-constexpr double MAX_RUDDER_ANGLE = PI / 6;
-constexpr double RUDDER_COEFFICIENT = 0.25;
-constexpr double RUDDER_DISTANCE = 2.0;
-constexpr double MASS = 2000.0;
-constexpr double MAX_POWER = 8948.4;
-constexpr double MAX_SPEED = 2.75;
-constexpr double MAX_PROP_SPEED = (MAX_RPM * PROP_RATIO) / PROP_PITCH;
-constexpr double MAX_FORCE = MAX_POWER / MAX_SPEED;
-constexpr double PROP_COEFFICIENT = MAX_FORCE / (MAX_PROP_SPEED * MAX_PROP_SPEED - MAX_SPEED * MAX_SPEED);
-constexpr double DRAG_COEFFICIENT = MAX_FORCE / (MAX_SPEED * MAX_SPEED * MAX_SPEED);
+
+/* The boat's characteristics: the 11 model parameters of VehicleState.h:86-96 (compile-time constants in the reference,
+ * marked "should allow setting of boat characteristics", :84) and what estimate() derives from them (:98-101), plus
+ * the reciprocals and products the device code multiplies by.  Per problem, in the problem record (a fleet may mix
+ * hulls); every access is wave-uniform.  make_model() is the ONLY place the derived fields are computed, on the host,
+ * in IEEE double with the reference's expressions: the default hull reproduces the reference's constants bit for bit. */
+struct Model {
+    double idle_rpm, max_rpm, max_rpm_change_rate, prop_ratio, prop_pitch, max_rudder_angle, rudder_coefficient,
+           rudder_distance, mass, max_power, max_speed;
+    double prop_coefficient, drag_coefficient;          /* VehicleState.h:100-101 */
+    double rpm_span;                                    /* max_rpm - idle_rpm */
+    double inv_prop_pitch, inv_rudder_distance, inv_mass;   /* RN(1/x): div_known */
+    double c_prop;                                      /* prop_ratio / prop_pitch: prop speed per rpm */
+    double kyaw;                                        /* rudder_coefficient / rudder_distance */
+    double pad0;                                        /* even number of doubles: the staging vectors behind it stay 16-byte aligned */
+};
+
+MPC_MODEL_FN inline Model make_model(double idle_rpm, double max_rpm, double max_rpm_change_rate, double prop_ratio,
+                                     double prop_pitch, double max_rudder_angle, double rudder_coefficient,
+                                     double rudder_distance, double mass, double max_power, double max_speed)
+{
+    Model m{};
+    m.idle_rpm = idle_rpm; m.max_rpm = max_rpm; m.max_rpm_change_rate = max_rpm_change_rate; m.prop_ratio = prop_ratio;
+    m.prop_pitch = prop_pitch; m.max_rudder_angle = max_rudder_angle; m.rudder_coefficient = rudder_coefficient;
+    m.rudder_distance = rudder_distance; m.mass = mass; m.max_power = max_power; m.max_speed = max_speed;
+    const double max_prop_speed = (max_rpm * prop_ratio) / prop_pitch;                     /* :98 */
+    const double max_force = max_power / max_speed;                                        /* :99 */
+    m.prop_coefficient = max_force / (max_prop_speed * max_prop_speed - max_speed * max_speed);   /* :100 */
+    m.drag_coefficient = max_force / (max_speed * max_speed * max_speed);                  /* :101 */
+    m.rpm_span = max_rpm - idle_rpm;
+    m.inv_prop_pitch = 1.0 / prop_pitch; m.inv_rudder_distance = 1.0 / rudder_distance; m.inv_mass = 1.0 / mass;
+    m.c_prop = prop_ratio / prop_pitch;
+    m.kyaw = rudder_coefficient / rudder_distance;
+    return m;
+}
+
+/* the reference's hull, VehicleState.h:86-96 */
+MPC_MODEL_FN inline Model default_model()
+{
+    return make_model(0.0, 3200.0, 1000.0, 0.389105058, 20.0, PI / 6, 0.25, 2.0, 2000.0, 8948.4, 2.75);
+}
 
 struct Weights { double wd, wh, ws; };
 
@@ -67,9 +92,9 @@ struct Weights { double wd, wh, ws; };
 struct Veh { double x, y, h, v, rpm, cmg, sog; };
 
 /* VehicleState.h:20-22 */
-MPC_MODEL_FN inline double rpm_from_speed(double speed)
+MPC_MODEL_FN inline double rpm_from_speed(double speed, const Model &M)
 {
-    return IDLE_RPM + (speed / MAX_SPEED) * (MAX_RPM - IDLE_RPM);
+    return M.idle_rpm + (speed / M.max_speed) * (M.max_rpm - M.idle_rpm);
 }
 
 /* a / b on the device as q = a*y, q + (a - b*q)*y with y = RN(1/b): three instructions instead of the ~25 of the IEEE
@@ -126,12 +151,12 @@ __device__ inline void heading_sincos(double h, double &sin_h, double &cos_h)
 /* STRIDE: distance between schedule rows; 0 = every substep uses row 0 (a uniform schedule held in registers). */
 template <int STRIDE = SUB_STRIDE>
 MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, const double *sub, int n_sub,
-                                    double cx, double cy)
+                                    double cx, double cy, const Model &M)
 {
     if (rudder < -1) rudder = -1; else if (rudder > 1) rudder = 1;
     if (throttle < 0) throttle = 0; else if (throttle > 1) throttle = 1;
-    const double target_rpm = IDLE_RPM + throttle * (MAX_RPM - IDLE_RPM);
-    const double rudder_angle = rudder * MAX_RUDDER_ANGLE;
+    const double target_rpm = M.idle_rpm + throttle * (M.max_rpm - M.idle_rpm);
+    const double rudder_angle = rudder * M.max_rudder_angle;
     const double cos_ra = cos(rudder_angle), sin_ra = sin(rudder_angle);
     double dx = 0, dy = 0, d_time = 1;
     for (int k = 0; k < n_sub; k++) {
@@ -139,17 +164,18 @@ MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, co
         /* 1/dt: the schedule rows carry it (host-computed, correctly rounded); a bare dt (STRIDE 0) is divided once */
         const double inv_dt = STRIDE == SUB_STRIDE ? sub[k * STRIDE + 5] : 1.0 / d_time;
         double rcr = div_known(target_rpm - s.rpm, d_time, inv_dt);
-        if (rcr > MAX_RPM_CHANGE_RATE) rcr = MAX_RPM_CHANGE_RATE;
-        else if (rcr < -MAX_RPM_CHANGE_RATE) rcr = -MAX_RPM_CHANGE_RATE;
+        if (rcr > M.max_rpm_change_rate) rcr = M.max_rpm_change_rate;
+        else if (rcr < -M.max_rpm_change_rate) rcr = -M.max_rpm_change_rate;
         s.rpm += rcr * d_time;
 
-        const double prop_rpm = PROP_RATIO * s.rpm;
-        const double prop_speed = div_known(prop_rpm, PROP_PITCH, 1.0 / PROP_PITCH);
+        const double prop_rpm = M.prop_ratio * s.rpm;
+        const double prop_speed = div_known(prop_rpm, M.prop_pitch, M.inv_prop_pitch);
         const double rudder_speed = fmax(sqrt(prop_speed), s.v);
-        const double thrust = PROP_COEFFICIENT * (prop_speed * prop_speed - s.v * s.v);
+        const double thrust = M.prop_coefficient * (prop_speed * prop_speed - s.v * s.v);
         const double thrust_fwd = thrust * cos_ra;
         const double rudder_speed_yaw = rudder_speed * sin_ra;
-        const double yaw_rate = RUDDER_COEFFICIENT * rudder_speed_yaw / RUDDER_DISTANCE;
+        /* (coefficient * x) / distance; by the reference's 2.0 the reciprocal form is exact */
+        const double yaw_rate = div_known(M.rudder_coefficient * rudder_speed_yaw, M.rudder_distance, M.inv_rudder_distance);
 
         /* heading = fmod(heading + yaw_rate*dt, 2pi); if (< 0) += 2pi.  For an argument in (-2pi, 4pi) -- every
          * substep of a real schedule -- fmod is an exact conditional subtraction (Sterbenz) or the identity, written as
@@ -161,8 +187,8 @@ MPC_MODEL_FN inline void strict_level(Veh &s, double rudder, double throttle, co
         s.h = h;
 
         const double speed = s.v;
-        const double drag = speed * speed * speed * DRAG_COEFFICIENT;
-        s.v += div_known(thrust_fwd - drag, MASS, 1.0 / MASS) * d_time;
+        const double drag = speed * speed * speed * M.drag_coefficient;
+        s.v += div_known(thrust_fwd - drag, M.mass, M.inv_mass) * d_time;
         const double delta = s.v * d_time;
 #if defined(__HIP_DEVICE_COMPILE__)
         double sin_h, cos_h;
@@ -267,11 +293,11 @@ __device__ inline double fast_exp_nonneg(double x)
 struct FastLevelCoef { double target_rpm, kpc, kyaw; };   /* thrust_fwd = kpc * (ps^2 - v^2);  yaw_rate = kyaw * rudder_speed */
 
 template <bool LEAN = false>
-__device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle)
+__device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle, const Model &M)
 {
     rudder = fmin(fmax(rudder, -1.0), 1.0);
     throttle = fmin(fmax(throttle, 0.0), 1.0);
-    const double x = rudder * MAX_RUDDER_ANGLE, x2 = x * x;
+    const double x = rudder * M.max_rudder_angle, x2 = x * x;
     /* the two chains alternate in the source: inline asm (LEAN) keeps its source order */
     double ps = -1.0 / 6227020800.0;                                   /* -1/13! */
     double pc = -1.0 / 87178291200.0;                                  /* -1/14! */
@@ -288,7 +314,7 @@ __device__ inline FastLevelCoef fast_level_coef(double rudder, double throttle)
     pc = fma(pc, x2, -0.5);
     const double sin_ra = fma(-(x * x2), ps, x);
     const double cos_ra = fma(pc, x2, 1.0);
-    return FastLevelCoef{throttle * MAX_RPM, PROP_COEFFICIENT * cos_ra, (RUDDER_COEFFICIENT / RUDDER_DISTANCE) * sin_ra};
+    return FastLevelCoef{fma(throttle, M.rpm_span, M.idle_rpm), M.prop_coefficient * cos_ra, M.kyaw * sin_ra};
 }
 
 /* One Euler substep, 27 FP64 instructions (VehicleState.h:111-148 restated for throughput):
@@ -334,9 +360,8 @@ __device__ inline void fast_substep(double &m, double &v, double &sh, double &ch
  * must not see 0 or a negative rounding residue); 1e-15 relative on prop_speed is far below the model's needs. */
 struct FastSlew { double m, sc, pst, sgn; };
 
-__device__ inline FastSlew fast_slew_begin(double rpm, double target_rpm)
+__device__ inline FastSlew fast_slew_begin(double rpm, double target_rpm, double C_PROP)
 {
-    constexpr double C_PROP = PROP_RATIO / PROP_PITCH;
     const double e = rpm - target_rpm;
     FastSlew z;
     z.m = fabs(e);
@@ -348,13 +373,13 @@ __device__ inline FastSlew fast_slew_begin(double rpm, double target_rpm)
 
 /* STRIDE 0: every substep of the level uses schedule row 0 (held in registers by the caller) */
 template <int STRIDE = SUB_STRIDE, bool LEAN = false>
-__device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
+__device__ inline void fast_level(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub, const Model &M)
 {
-    const FastLevelCoef c = fast_level_coef<LEAN>(rudder, throttle);
-    FastSlew z = fast_slew_begin(s.rpm, c.target_rpm);
+    const FastLevelCoef c = fast_level_coef<LEAN>(rudder, throttle, M);
+    FastSlew z = fast_slew_begin(s.rpm, c.target_rpm, M.c_prop);
     if (STRIDE == 0) {
         const double dt = sub[0], max_step = sub[1], dtm = sub[2], inv_dt = sub[5];
-        const double kpcm = c.kpc * dtm, dm = DRAG_COEFFICIENT * dtm, kyaw_dt = c.kyaw * dt;
+        const double kpcm = c.kpc * dtm, dm = M.drag_coefficient * dtm, kyaw_dt = c.kyaw * dt;
         double xs = s.x * inv_dt, ys = s.y * inv_dt;
 #ifdef MPC_SUBSTEP_UNROLL
 #pragma unroll MPC_SUBSTEP_UNROLL
@@ -372,7 +397,7 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
             const double *q = sub + k * STRIDE;
             dt = q[0];
             fast_substep<false>(z.m, s.v, s.sh, s.ch, s.x, s.y, z.sc, z.pst, q[1], c.kpc * q[2],
-                                DRAG_COEFFICIENT * q[2], c.kyaw * dt, dt);
+                                M.drag_coefficient * q[2], c.kyaw * dt, dt);
         }
         if (n_sub > 0) s.delta = s.v * dt;
     }
@@ -383,12 +408,13 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
  * (:48-54: steps of 0.1 s and a remainder; the 1-s level of controller.cpp:149 is ten of 0.1 s and one of 1.4e-16 s).
  * The head runs like a uniform level (schedule row in registers, position in units of dt), the tail as one plain substep. */
 template <bool LEAN = false>
-__device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub)
+__device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub,
+                                               const Model &M)
 {
-    const FastLevelCoef c = fast_level_coef<LEAN>(rudder, throttle);
-    FastSlew z = fast_slew_begin(s.rpm, c.target_rpm);
+    const FastLevelCoef c = fast_level_coef<LEAN>(rudder, throttle, M);
+    FastSlew z = fast_slew_begin(s.rpm, c.target_rpm, M.c_prop);
     const double dt = sub[0], max_step = sub[1], dtm = sub[2], inv_dt = sub[5];
-    const double kpcm = c.kpc * dtm, dm = DRAG_COEFFICIENT * dtm, kyaw_dt = c.kyaw * dt;
+    const double kpcm = c.kpc * dtm, dm = M.drag_coefficient * dtm, kyaw_dt = c.kyaw * dt;
     double xs = s.x * inv_dt, ys = s.y * inv_dt;
 #ifdef MPC_SUBSTEP_UNROLL
 #pragma unroll MPC_SUBSTEP_UNROLL
@@ -398,7 +424,7 @@ __device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double
     s.x = xs * dt; s.y = ys * dt;
     const double *q = sub + (n_sub - 1) * SUB_STRIDE;
     const double dl = q[0];
-    fast_substep<false>(z.m, s.v, s.sh, s.ch, s.x, s.y, z.sc, z.pst, q[1], c.kpc * q[2], DRAG_COEFFICIENT * q[2],
+    fast_substep<false>(z.m, s.v, s.sh, s.ch, s.x, s.y, z.sc, z.pst, q[1], c.kpc * q[2], M.drag_coefficient * q[2],
                         c.kyaw * dl, dl);
     s.delta = s.v * dl;
     s.rpm = fma(z.sgn, z.m, c.target_rpm);

@@ -186,7 +186,8 @@ __device__ inline Child make_child(const DevProblem &P, const double *cpL, const
     control_pick(P, A.last_r[par], A.last_t[par], j, r, t);
     Child ch;
     ch.s = Veh{A.x[par], A.y[par], A.h[par], A.v[par], A.rpm[par], 0.0, 0.0};
-    strict_level(ch.s, r, t, subL, P.nsub, P.cx, P.cy);                               /* controller.cpp:149-150 */
+    const Model M = P.model;                                                          /* wave-uniform: scalar registers */
+    strict_level(ch.s, r, t, subL, P.nsub, P.cx, P.cy, M);                              /* controller.cpp:149-150 */
     const Weights w{P.wd, P.wh, P.ws};
     ch.score = strict_score(cpL + level * CP_STRIDE, ch.s, w);                        /* :155 */
     ch.cum = A.cum[par] + ch.score;                                                   /* :156 */
@@ -308,8 +309,9 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
     control_pick(P, A.last_r[par], A.last_t[par], j, ch.r, ch.t);
     ch.s.x = A.x[par]; ch.s.y = A.y[par]; ch.s.sh = A.h[par]; ch.s.ch = A.cmg[par]; ch.s.v = A.v[par]; ch.s.rpm = A.rpm[par];
     ch.s.delta = 0;
-    if (P.head_uniform) fast_level_head_uniform<true>(ch.s, ch.r, ch.t, subL, P.nsub);      /* the reference's own 1-s level */
-    else fast_level<SUB_STRIDE, true>(ch.s, ch.r, ch.t, subL, P.nsub);
+    const Model M = P.model;
+    if (P.head_uniform) fast_level_head_uniform<true>(ch.s, ch.r, ch.t, subL, P.nsub, M);      /* the reference's own 1-s level */
+    else fast_level<SUB_STRIDE, true>(ch.s, ch.r, ch.t, subL, P.nsub, M);
     const Weights w{P.wd, P.wh, P.ws};
     ch.score = fast_score<true>(cpL + level * CP_STRIDE, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
     ch.cum = A.cum[par] + ch.score;
@@ -406,10 +408,11 @@ __device__ inline void strict_path(const DevProblem &P, const double *cpL, const
 {
     Veh s{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
     const Weights w{P.wd, P.wh, P.ws};
+    const Model M = P.model;
     last = 0; cum = 0;
     if (traj) traj[0] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l <= L; l++) {
-        strict_level(s, pc.r[l], pc.t[l], subL, P.nsub, P.cx, P.cy);
+        strict_level(s, pc.r[l], pc.t[l], subL, P.nsub, P.cx, P.cy, M);
         last = strict_score(cpL + l * CP_STRIDE, s, w);
         cum += last;
         if (traj) traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog, pc.r[l], pc.t[l], cum};
@@ -795,6 +798,7 @@ static int solve_tree_checked(mpc_hip_handle *h, const mpc_problem *h_problem, i
                 return MPC_ERR_INVALID;
             }
     if (int s = mpc_use_device(h)) return s;
+    if (precision == MPC_PREC_FAST) if (int s = mpc_check_fast_model(h, 1)) return s;
     if (max_levels <= 0) {                        /* controller.cpp:80 never entered -> :196 */
         memset(h_result, 0, sizeof *h_result);
         h_result->status = MPC_ERR_NO_ITERATION;

@@ -21,7 +21,7 @@ class VehicleState
 {
 public:
     /* rpm follows from the speed, VehicleState.h:20-22; the reference leaves the two derived members unset */
-    VehicleState(State s) : rpm(mpc::rpm_from_speed(s.speed())), courseMadeGood(0), speedOverGround(0), state(s) {}
+    VehicleState(State s) : rpm(mpc::rpm_from_speed(s.speed(), mpc::default_model())), courseMadeGood(0), speedOverGround(0), state(s) {}
 
     VehicleState simulate(double rudder, double throttle, double t) const
     {
@@ -35,6 +35,7 @@ public:
         double rows[SUB_STRIDE * kMaxSubsteps];
         int n = 0;
         VehicleState out(*this);
+        const mpc::Model hull = mpc::default_model();          /* the reference's compile-time hull, VehicleState.h:86-101 */
         mpc::Veh v{state.x(), state.y(), state.heading(), state.speed(), rpm, courseMadeGood, speedOverGround};
         double elapsed = state.time();
         while (t > 0) {
@@ -43,9 +44,9 @@ public:
             rows[n * SUB_STRIDE] = d;
             rows[n * SUB_STRIDE + 5] = 1.0 / d;          /* the schedule row's reciprocal slot (the device's div_known reads it) */
             elapsed += d;
-            if (++n == kMaxSubsteps) { mpc::strict_level(v, rudder, throttle, rows, n, estimatedCurrent.first, estimatedCurrent.second); n = 0; }
+            if (++n == kMaxSubsteps) { mpc::strict_level(v, rudder, throttle, rows, n, estimatedCurrent.first, estimatedCurrent.second, hull); n = 0; }
         }
-        if (n) mpc::strict_level(v, rudder, throttle, rows, n, estimatedCurrent.first, estimatedCurrent.second);
+        if (n) mpc::strict_level(v, rudder, throttle, rows, n, estimatedCurrent.first, estimatedCurrent.second, hull);
         out.state = State(v.x, v.y, v.h, v.v, elapsed);
         out.rpm = v.rpm; out.courseMadeGood = v.cmg; out.speedOverGround = v.sog;
         return out;

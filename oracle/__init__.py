@@ -36,6 +36,13 @@ class Config(C.Structure):
         "last_rudder", "last_throttle", "current_x", "current_y")]
 
 
+class Model(C.Structure):
+    """orc_model: the boat's 11 parameters (VehicleState.h:86-96)"""
+    _fields_ = [(n, C.c_double) for n in (
+        "idle_rpm", "max_rpm", "max_rpm_change_rate", "prop_ratio", "prop_pitch", "max_rudder_angle",
+        "rudder_coefficient", "rudder_distance", "mass", "max_power", "max_speed")]
+
+
 class MpcState(C.Structure):
     _fields_ = [("v", Vehicle), ("last_rudder", C.c_double), ("last_throttle", C.c_double),
                 ("score", C.c_double)]
@@ -76,6 +83,8 @@ def lib():
     L = C.CDLL(_LIB_PATH)
     dp = C.POINTER(C.c_double)
     L.orc_default_config.argtypes = [C.POINTER(Config)]
+    L.orc_default_model.argtypes = [C.POINTER(Model)]; L.orc_default_model.restype = None
+    L.orc_set_model.argtypes = [C.POINTER(Model)]; L.orc_set_model.restype = None
     L.orc_vehicle_from_state.argtypes = [State]; L.orc_vehicle_from_state.restype = Vehicle
     L.orc_schedule.argtypes = [C.c_double, dp, C.c_int]; L.orc_schedule.restype = C.c_int
     L.orc_estimate.argtypes = [C.POINTER(Vehicle)] + [C.c_double] * 5
@@ -108,6 +117,19 @@ def lib():
 
 
 # ---- convenience wrappers ---------------------------------------------------------------------------
+def set_model(**kw):
+    """process-wide hull of the oracle: the reference's (VehicleState.h:86-96) with the given parameters replaced;
+    set_model() with no arguments restores the reference's"""
+    m = Model()
+    lib().orc_default_model(C.byref(m))
+    for k, v in kw.items():
+        if not hasattr(m, k):
+            raise AttributeError(k)
+        setattr(m, k, float(v))
+    lib().orc_set_model(C.byref(m))
+    return m
+
+
 def default_config(**kw):
     c = Config()
     lib().orc_default_config(C.byref(c))

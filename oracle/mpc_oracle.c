@@ -15,21 +15,38 @@
 #include <string.h>
 
 /* ---- model constants, VehicleState.h:86-101 --------------------------------------------------- */
-#define IDLE_RPM 0.0
-#define MAX_RPM 3200.0
-#define MAX_RPM_CHANGE_RATE 1000.0
-#define PROP_RATIO 0.389105058
-#define PROP_PITCH 20.0
-#define MAX_RUDDER_ANGLE (M_PI / 6)
-#define RUDDER_COEFFICIENT 0.25
-#define RUDDER_DISTANCE 2.0
-#define MASS 2000.0
-#define MAX_POWER 8948.4
-#define MAX_SPEED 2.75
-static const double k_max_prop_speed = (MAX_RPM * PROP_RATIO) / PROP_PITCH;
-static const double k_max_force = MAX_POWER / MAX_SPEED;
+/* The reference compiles these in ("TODO! -- should allow setting of boat characteristics", :84); the oracle keeps
+ * them in ONE process-wide record so that the product's mpc_hip_set_model can be checked against the same
+ * arithmetic with another hull (orc_set_model; not thread-safe against concurrent evaluation: set it between
+ * runs).  The default record holds the reference's literals; the derived values follow :98-101 expression by
+ * expression, in double, so the default hull gives the bits the compile-time constants gave. */
+static orc_model g_model = {0.0, 3200.0, 1000.0, 0.389105058, 20.0, M_PI / 6, 0.25, 2.0, 2000.0, 8948.4, 2.75};
+#define IDLE_RPM (g_model.idle_rpm)
+#define MAX_RPM (g_model.max_rpm)
+#define MAX_RPM_CHANGE_RATE (g_model.max_rpm_change_rate)
+#define PROP_RATIO (g_model.prop_ratio)
+#define PROP_PITCH (g_model.prop_pitch)
+#define MAX_RUDDER_ANGLE (g_model.max_rudder_angle)
+#define RUDDER_COEFFICIENT (g_model.rudder_coefficient)
+#define RUDDER_DISTANCE (g_model.rudder_distance)
+#define MASS (g_model.mass)
+#define MAX_POWER (g_model.max_power)
+#define MAX_SPEED (g_model.max_speed)
+#define k_max_prop_speed ((MAX_RPM * PROP_RATIO) / PROP_PITCH)
+#define k_max_force (MAX_POWER / MAX_SPEED)
 #define PROP_COEFFICIENT (k_max_force / (k_max_prop_speed * k_max_prop_speed - MAX_SPEED * MAX_SPEED))
 #define DRAG_COEFFICIENT (k_max_force / (MAX_SPEED * MAX_SPEED * MAX_SPEED))
+
+void orc_default_model(orc_model *m)
+{
+    const orc_model d = {0.0, 3200.0, 1000.0, 0.389105058, 20.0, M_PI / 6, 0.25, 2.0, 2000.0, 8948.4, 2.75};
+    *m = d;
+}
+
+void orc_set_model(const orc_model *m)
+{
+    if (m) g_model = *m; else orc_default_model(&g_model);
+}
 
 void orc_default_config(orc_config *c)
 {

@@ -58,6 +58,14 @@ typedef struct {
     double   best_cumulative;/* its cumulative Score (controller.cpp:156) */
 } orc_level_result;
 
+/* the boat's 11 parameters, VehicleState.h:86-96, in the reference's order */
+typedef struct {
+    double idle_rpm, max_rpm, max_rpm_change_rate, prop_ratio, prop_pitch, max_rudder_angle, rudder_coefficient,
+           rudder_distance, mass, max_power, max_speed;
+} orc_model;
+void   orc_default_model(orc_model *m);
+void   orc_set_model(const orc_model *m);            /* process-wide; NULL restores the reference's hull */
+
 void   orc_default_config(orc_config *c);
 orc_vehicle orc_vehicle_from_state(orc_state s);                                  /* VehicleState.h:20-22 */
 int    orc_schedule(double t, double *out, int cap);                              /* VehicleState.h:49-53 */
