@@ -115,6 +115,8 @@ def main():
                     help="HIP events ride on every n-th solve's dispatches inside the timed region (1 = every solve)")
     ap.add_argument("--combine-batch", type=int, default=64,
                     help="solves per all-gather of the shard winners (multi-GPU runs)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="two kernels per solve (rollouts, finish) instead of the deferred finish (mpc_hip_set_pipeline)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -219,6 +221,9 @@ def main():
             if combiner:
                 combiner.submit()
 
+        # a stream of solves: each run's finish rides in the next run's rollout launch (one dispatch per solve); the
+        # results are bit for bit those of the two-kernel form (tests/test_gpu_pipeline.py)
+        solver.set_pipeline(not args.no_pipeline)
         solver.set_timing(0)
         t_ramp = time.perf_counter()
         while time.perf_counter() - t_ramp < args.ramp_seconds and args.workload == "config2":
@@ -236,12 +241,14 @@ def main():
         for _ in range(args.steps):
             step()
         combined = combiner.flush() if combiner else None      # every solve of the timed region is combined by here
+        solver.flush()                                         # ... and finished (the last solve's deferred finish)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         runs, k1_ms_sum, total_ms_sum = solver.timing(reset=True)
         res = solver.fetch()[0]
+        solver.set_pipeline(False)  # the latency loop is one synchronous solve at a time
         solver.set_timing(0)       # the latency loop below is timed by the host clock: no events on its dispatches (~5 us each)
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -286,7 +293,7 @@ def main():
             "config": {"workload": what, "candidates_per_gpu": n_problems * count, "problems_per_gpu": n_problems,
                        "depth": depth, "substeps_per_level": nsub,
                        "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
-                       "selection": "last_step",
+                       "selection": "last_step", "deferred_finish": not args.no_pipeline,
                        "parallelism": ("candidate shards; per %d solves one async RCCL all-gather of the packed winners, strict re-score of "
                                        "cross-shard near-ties (mpc_hip_rescore_tied_shards), second all-gather, combine: the reference's "
                                        "first strict minimum across GPUs" % args.combine_batch if combine else

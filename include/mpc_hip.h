@@ -283,6 +283,22 @@ int         mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathered
  * No counterpart in the reference. */
 int         mpc_hip_rescore_tied_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
                                         uint32_t my_shard, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows);
+/* Streams of solves: the deferred finish.  A run is two kernels -- the rollouts with their workgroup argmins, then one
+ * small workgroup per problem that reduces them, decides near-ties with the strict model and writes winners, result
+ * and trajectory -- and for a 65,536-candidate solve the second one, with its dispatch boundary, is 15 % of the time.
+ * With the pipeline on, mpc_hip_run_* enqueues only the rollouts and leaves that finish PENDING; the next run's rollout
+ * launch carries it as one extra workgroup per problem, beside a thousand workgroups that do not wait for it (the
+ * working memory between the two kernels is double-buffered), so a stream costs one dispatch per solve.  Results of
+ * run n therefore appear on the stream with run n+1 -- or at once with any call that needs them, each of which first
+ * launches a pending finish on its own: mpc_hip_fetch_results, mpc_hip_copy_winners, mpc_hip_device_winners,
+ * mpc_hip_timing, mpc_hip_synchronize, mpc_hip_upload_problems*, mpc_hip_set_model, mpc_hip_estimate_currents,
+ * mpc_hip_set_pipeline(h, 0), and mpc_hip_flush, for callers that consume the winner sink on the stream (flush before
+ * the collective that reads it).  The winner sink in force when a run was ENQUEUED is the one its finish writes.
+ * Results are bit for bit those of the two-kernel form.  The one-call forms (mpc_hip_eval_*) fetch and therefore
+ * never defer; runs that have no fused variant (strict precision, non-uniform schedules, >= 2^20 candidates) finish
+ * the pending solve with a launch of its own first.  Off by default.  No counterpart in the reference. */
+int         mpc_hip_set_pipeline(mpc_hip_handle *h, int on);
+int         mpc_hip_flush(mpc_hip_handle *h);
 /* Which runs carry HIP events: every `period`-th run of the handle (1 = all, the default; 0 = none).  The events
  * ride ON the run's two dispatches (the kernels' own begin/end timestamps), but a dispatch with events still
  * costs ~5 us more than one without, so throughput callers sample (bench.py: every 8th) or switch them off.

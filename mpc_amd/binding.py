@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_substep_schedule", "mpc_hip_default_model", "mpc_hip_set_model", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
     "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_run_seeded", "mpc_hip_run_seeded_static", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
-    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_rescore_tied_shards", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
+    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_rescore_tied_shards", "mpc_hip_set_pipeline", "mpc_hip_flush", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
 )
 
 
@@ -146,6 +146,8 @@ def load_library(path=None):
     L.mpc_hip_estimate_currents.argtypes = [vp, C.POINTER(HistorySample), C.POINTER(C.c_uint32), C.c_uint32, dp, C.c_uint32,
                                             i32, dp]
     L.mpc_hip_set_winner_sink.argtypes = [vp, vp]
+    L.mpc_hip_set_pipeline.argtypes = [vp, i32]
+    L.mpc_hip_flush.argtypes = [vp]
     L.mpc_hip_set_timing.argtypes = [vp, C.c_uint32]
     L.mpc_hip_timing.argtypes = [vp, i32, C.POINTER(u64), dp, dp]
     L.mpc_hip_solve_tree.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, C.POINTER(TreeLevel), RP]
@@ -363,6 +365,14 @@ class Solver:
     def set_winner_sink(self, d_dst):
         """runs also write their packed winners to d_dst (a device tensor / pointer; None: off)"""
         _check(self._L.mpc_hip_set_winner_sink(self._h, _ptr(d_dst)))
+
+    def set_pipeline(self, on):
+        """deferred finish for streams of solves (mpc_hip.h): run n's results appear with run n+1 or on demand"""
+        _check(self._L.mpc_hip_set_pipeline(self._h, int(bool(on))))
+
+    def flush(self):
+        """launch a pending finish now (before a collective that reads the winner sink on the stream)"""
+        _check(self._L.mpc_hip_flush(self._h))
 
     def set_timing(self, period):
         """HIP events on every `period`-th run (1 = all, 0 = none)."""

@@ -99,6 +99,7 @@ extern "C" int mpc_hip_estimate_currents(mpc_hip_handle *h, const mpc_history_sa
         }
     }
     if (int s = mpc_use_device(h)) return s;
+    if (int s = mpc_flush_pending(h)) return s;          /* a pending finish reads the problem records this may rewrite */
     const size_t b_samples = sizeof(mpc_history_sample) * (size_t)n * stride;
     const size_t b_counts = (sizeof(uint32_t) * n + 15) & ~(size_t)15;
     const size_t b_actual = sizeof(double) * 3 * n, b_out = sizeof(double) * 2 * n;

@@ -60,6 +60,7 @@ static int static_scratch_ptr(int device, void **out)
 /* ------------------------------------------------------------------------------------------------------ */
 /* host side                                                                                               */
 /* ------------------------------------------------------------------------------------------------------ */
+static int flush_pending(mpc_hip_handle *h);
 int mpc_use_device(const mpc_hip_handle *h)
 {
     HIP_TRY(hipSetDevice(h->device));
@@ -119,6 +120,7 @@ extern "C" int mpc_hip_create(int device, void *stream, mpc_hip_handle **out)
     h->device = device;
     h->ev.assign(4 * TIMING_RING, nullptr);
     h->timed.assign(TIMING_RING, 0);
+    h->total_from_k1.assign(TIMING_RING, 0);
     const int s = [&]() -> int {
         HIP_TRY(hipSetDevice(device));
         if (stream) h->stream = (hipStream_t)stream;
@@ -146,8 +148,9 @@ extern "C" void mpc_hip_destroy(mpc_hip_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_probs); (void)hipHostFree(h->h_probs);
     (void)hipFree(h->d_results); (void)hipHostFree(h->h_results);
-    (void)hipFree(h->d_winners); (void)hipFree(h->d_list_count); (void)hipFree(h->d_pcnt); (void)hipFree(h->d_snap);
-    (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord); (void)hipFree(h->d_keys);
+    (void)hipFree(h->d_winners); (void)hipFree(h->d_list_count); (void)hipFree(h->d_pcnt);
+    (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord);
+    for (WorkMem &w : h->wm) { (void)hipFree(w.d_keys); (void)hipFree(w.d_snap); (void)hipFree(w.d_pkey); (void)hipFree(w.d_pord); (void)hipFree(w.d_pcnt); }
     (void)hipFree(h->d_controls); (void)hipFree(h->d_models); (void)hipFree(h->d_tied_rows); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
     mpc_tree_free(h);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -159,6 +162,7 @@ extern "C" int mpc_hip_synchronize(mpc_hip_handle *h)
 {
     if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
     if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MPC_OK;
 }
@@ -271,6 +275,7 @@ extern "C" int mpc_hip_set_model(mpc_hip_handle *h, const mpc_model *models, uin
         ok[i] = model_fits_fast(packed[i]);
     }
     if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;
     if (n_models > h->cap_models) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         (void)hipFree(h->d_models); h->d_models = nullptr; h->cap_models = 0;
@@ -322,6 +327,7 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
     if (!h || !h_problems || n_problems == 0) { mpc_set_err("upload_problems: NULL handle/problems or zero problems"); return MPC_ERR_INVALID; }
     if (n_problems > 65535) { mpc_set_err("more than 65535 problems in one batch"); return MPC_ERR_TOO_LARGE; }
     if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;          /* a pending finish reads the resident problems */
     for (uint32_t p = 0; p < n_problems; p++)
         if (int s = mpc_check_problem(&h_problems[p], MPC_PREC_F64)) return s;
     if (int s = mpc_ensure_problem_capacity(h, n_problems)) return s;
@@ -341,13 +347,33 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
 #define K1_LDS_BASE (sizeof(double) * (MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + sizeof(uint64_t) * 12)
 #define K1_LDS_LIMIT ((size_t)64 * 1024)
 
-static int ensure_keys(mpc_hip_handle *h, size_t need)
+/* ---- the deferred finish (mpc_hip_set_pipeline) ----------------------------------------------------------------
+ * A run is K1 (rollouts) + K2 (finish).  With the pipeline on, a run enqueues only K1 and leaves its K2 PENDING; the
+ * next run's K1 launch carries it as one extra workgroup per problem (rollout_kernel<.., FUSE>), and any call that
+ * needs the results (fetch, winners, upload, synchronize, ...) launches it on its own first.  Working memory that K1
+ * writes and K2 reads is double-buffered (h->wm[2]) so that K1 of solve n+1 never overwrites what K2 of solve n reads. */
+static int flush_pending(mpc_hip_handle *h)
 {
-    if (need <= h->cap_keys) return MPC_OK;
+    if (!h->pending) return MPC_OK;
+    hipEvent_t *ev = &h->ev[4 * h->pend_slot];
+    hipEvent_t k2a = h->pend_timed ? ev[2] : nullptr, k2b = h->pend_timed ? ev[3] : nullptr;
+    const dim3 grid(h->pend_n_probs), blk(256);
+    if (h->pend_seeded) hipExtLaunchKernelGGL((finish_kernel<true>), grid, blk, 0, h->stream, k2a, k2b, 0, h->pend);
+    else hipExtLaunchKernelGGL((finish_kernel<false>), grid, blk, 0, h->stream, k2a, k2b, 0, h->pend);
+    h->pending = false;
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_flush_pending(mpc_hip_handle *h) { return flush_pending(h); }
+
+static int ensure_buffer(mpc_hip_handle *h, void **buf, size_t *cap, size_t need_bytes)
+{
+    if (need_bytes <= *cap) return MPC_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(h->d_keys); h->d_keys = nullptr; h->cap_keys = 0;
-    HIP_TRY(hipMalloc(&h->d_keys, sizeof(double) * need));
-    h->cap_keys = need;
+    (void)hipFree(*buf); *buf = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc(buf, need_bytes));
+    *cap = need_bytes;
     return MPC_OK;
 }
 
@@ -383,8 +409,14 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     while (!seeded && block > 64 && K1_LDS_BASE + sizeof(float) * 2 * (size_t)h->depth[0] * block > K1_LDS_LIMIT) block >>= 1;
     const uint32_t cpb = block;                   /* candidates per workgroup */
     const uint64_t nblk64 = (count + cpb - 1) / cpb;
-    if (nblk64 > 0x7FFFFFFFull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
+    if (nblk64 > 0x7FFFFFFEull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
     const uint32_t nblk = (uint32_t)nblk64;
+
+    /* which half of the working memory this run writes: the other one may still be read by a pending finish */
+    const bool pipelined = h->pipeline && !use_static;
+    if (h->pending && !pipelined) { if (int s = flush_pending(h)) return s; }
+    const int half = pipelined ? (h->pending ? 1 - h->pend_half : 0) : 0;
+    WorkMem &wm = h->wm[half];
     double *d_keys; uint64_t *d_pkey, *d_pord; uint32_t *d_pcnt;
     if (use_static) {
         if ((uint64_t)h->n_probs * count > MPC_STATIC_MAX_CANDIDATES) {
@@ -399,9 +431,18 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
         StaticScratch *S = (StaticScratch *)h->d_static_scratch;       /* the device address, never the symbol's name */
         d_keys = S->keys; d_pkey = S->pkey; d_pord = S->pord; d_pcnt = S->pcnt;
     } else {
-        if (int s = ensure_keys(h, (size_t)h->n_probs * count)) return s;
-        if (int s = mpc_ensure_partials(h, (size_t)h->n_probs * nblk)) return s;
-        d_keys = h->d_keys; d_pkey = h->d_pkey; d_pord = h->d_pord; d_pcnt = h->d_pcnt;
+        const size_t n_part = (size_t)h->n_probs * nblk;
+        if (half == 0) {                       /* half 0's triples are the tree search's too (h->d_pkey ...) */
+            if (int s = mpc_ensure_partials(h, n_part)) return s;
+            d_pkey = h->d_pkey; d_pord = h->d_pord; d_pcnt = h->d_pcnt;
+        } else {
+            if (int s = ensure_buffer(h, (void **)&wm.d_pkey, &wm.cap_pkey, sizeof(uint64_t) * n_part)) return s;
+            if (int s = ensure_buffer(h, (void **)&wm.d_pord, &wm.cap_pord, sizeof(uint64_t) * n_part)) return s;
+            if (int s = ensure_buffer(h, (void **)&wm.d_pcnt, &wm.cap_pcnt, sizeof(uint32_t) * n_part)) return s;
+            d_pkey = wm.d_pkey; d_pord = wm.d_pord; d_pcnt = wm.d_pcnt;
+        }
+        if (int s = ensure_buffer(h, (void **)&wm.d_keys, &wm.cap_keys, sizeof(double) * (size_t)h->n_probs * count)) return s;
+        d_keys = wm.d_keys;
     }
 
     /* per-level snapshots of every candidate (so the winner's trajectory needs no second rollout) while they
@@ -411,13 +452,8 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     const size_t snap_need = (size_t)h->n_probs * count * snap_depth * SNAP_FIELDS;
     double *d_snap = nullptr;
     if (!use_static && snap_need * sizeof(double) <= MPC_SNAPSHOT_BYTES_MAX) {
-        if (snap_need > h->cap_snap) {
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            (void)hipFree(h->d_snap); h->d_snap = nullptr; h->cap_snap = 0;
-            HIP_TRY(hipMalloc(&h->d_snap, sizeof(double) * snap_need));
-            h->cap_snap = snap_need;
-        }
-        d_snap = h->d_snap;
+        if (int s = ensure_buffer(h, (void **)&wm.d_snap, &wm.cap_snap, sizeof(double) * snap_need)) return s;
+        d_snap = wm.d_snap;
     }
     const int fast = precision == MPC_PREC_FAST;
     const double rel = fast ? MPC_REFINE_REL : 0.0;
@@ -426,36 +462,46 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     for (uint32_t p = 0; p < h->n_probs && uniform; p++)
         for (int s = 1; s < h->nsub[p]; s++)
             if (h->h_probs[p].sub[s * SUB_STRIDE] != h->h_probs[p].sub[0]) { uniform = false; break; }
-    hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
-    const dim3 grid(nblk, h->n_probs), blk(block);
-    /* explicit sets: all levels' controls of a workgroup are staged in LDS as FP32 (<= 64 KiB by the block choice) */
-    const size_t ctl_bytes = seeded ? 0 : sizeof(float) * 2 * (size_t)snap_depth * block;
+    const uint32_t slot = (uint32_t)(h->runs % TIMING_RING);
+    hipEvent_t *ev = &h->ev[4 * slot];
+    /* the pending finish rides along when this launch has a variant for it: fast uniform rollouts in one-wave
+     * workgroups (every throughput stream of small sets: config 2), the same kind of candidate source, the same batch */
+    const bool fuse = pipelined && h->pending && fast && uniform && block == 64 && h->pend_seeded == seeded &&
+                      h->pend_n_probs == h->n_probs;
+    if (h->pending && !fuse) { if (int s = flush_pending(h)) return s; }
+    const dim3 grid(nblk + (fuse ? 1u : 0u), h->n_probs), blk(block);
+    /* explicit sets: all levels' controls of a workgroup are staged in LDS as FP32 (<= 64 KiB by the block choice);
+     * a fused finish keeps its near-tie list (+ 16 words) in the same place */
+    size_t ctl_bytes = seeded ? 0 : sizeof(float) * 2 * (size_t)snap_depth * block;
+    if (fuse) ctl_bytes = std::max(ctl_bytes, sizeof(uint64_t) * (LIST_CAP + FINISH_LDS_WORDS));
     const size_t lds = K1_LDS_BASE + ctl_bytes;
     if (lds > K1_LDS_LIMIT) { mpc_set_err("rollout kernel: staged controls do not fit the workgroup's LDS"); return MPC_ERR_TOO_LARGE; }
-    /* timed runs carry their events ON the two dispatches (the kernels' own begin/end, as a profiler reads them):
+    /* timed runs carry their events ON the dispatches (the kernels' own begin/end, as a profiler reads them):
      * recording events between the launches instead costs ~4 barrier packets = 15 us per 59-us solve */
     const bool timed = h->timing_period && (h->runs % h->timing_period) == 0;
-    h->timed[h->runs % TIMING_RING] = timed;
+    h->timed[slot] = timed;
+    h->total_from_k1[slot] = 0;
+    if (fuse) h->total_from_k1[h->pend_slot] = 1;          /* that run's finish has no dispatch of its own: hidden in this K1 */
     hipEvent_t k1a = timed ? ev[0] : nullptr, k1b = timed ? ev[1] : nullptr;
-    hipEvent_t k2a = timed ? ev[2] : nullptr, k2b = timed ? ev[3] : nullptr;
+    const FinishArgs prev = fuse ? h->pend : FinishArgs{};
 #define LAUNCH_K1(PREC, SEEDED)                                                                               \
-    if (uniform) LAUNCH_K1U(PREC, SEEDED, true); else LAUNCH_K1U(PREC, SEEDED, false)
-#define LAUNCH_K1U(PREC, SEEDED, UNI)                                                                         \
-    hipExtLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth,  \
-                       d_pkey, d_pord, d_pcnt)
-    if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
+    if (uniform) LAUNCH_K1U(PREC, SEEDED, true, false); else LAUNCH_K1U(PREC, SEEDED, false, false)
+#define LAUNCH_K1U(PREC, SEEDED, UNI, FUSE)                                                                   \
+    hipExtLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI, FUSE>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
+                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth,     \
+                       d_pkey, d_pord, d_pcnt, prev)
+    if (fuse) { if (seeded) LAUNCH_K1U(MPC_PREC_FAST, true, true, true); else LAUNCH_K1U(MPC_PREC_FAST, false, true, true); }
+    else if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
     else { if (seeded) LAUNCH_K1(MPC_PREC_FAST, true); else LAUNCH_K1(MPC_PREC_FAST, false); }
 #undef LAUNCH_K1
 #undef LAUNCH_K1U
     HIP_TRY(hipGetLastError());
-#define LAUNCH_K2(SEEDED)                                                                                     \
-    hipExtLaunchKernelGGL((finish_kernel<SEEDED>), dim3(h->n_probs), dim3(256), 0, h->stream, k2a, k2b, 0, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, fast, (int)uniform, rel, nblk, cpb, d_pkey, d_pord, d_pcnt, d_keys, \
-                       d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->d_results)
-    if (seeded) LAUNCH_K2(true); else LAUNCH_K2(false);
-#undef LAUNCH_K2
-    HIP_TRY(hipGetLastError());
+    /* this run's finish: pending (pipeline) or launched right away */
+    h->pend = FinishArgs{h->d_probs, d_rud, d_thr, first, count, selection, fast, (int)uniform, rel, nblk, cpb,
+                         d_pkey, d_pord, d_pcnt, d_keys, d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->d_results};
+    h->pending = true; h->pend_seeded = seeded; h->pend_n_probs = h->n_probs; h->pend_half = half;
+    h->pend_slot = slot; h->pend_timed = timed;
+    if (!pipelined) { if (int s = flush_pending(h)) return s; }
     h->runs++;
     h->last_count = count; h->last_first = first; h->last_precision = precision; h->last_selection = selection;
     h->last_seeded = seeded; h->ran = true;
@@ -484,6 +530,22 @@ extern "C" int mpc_hip_run_seeded_static(mpc_hip_handle *h, uint64_t first_ordin
     return run_common(h, true, nullptr, nullptr, first_ordinal, count, precision, selection, d_cost_last, d_cost_cum, true);
 }
 
+extern "C" int mpc_hip_set_pipeline(mpc_hip_handle *h, int on)
+{
+    if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
+    if (int s = mpc_use_device(h)) return s;
+    if (!on) { if (int s = flush_pending(h)) return s; }
+    h->pipeline = on != 0;
+    return MPC_OK;
+}
+
+extern "C" int mpc_hip_flush(mpc_hip_handle *h)
+{
+    if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
+    if (int s = mpc_use_device(h)) return s;
+    return flush_pending(h);
+}
+
 extern "C" int mpc_hip_set_timing(mpc_hip_handle *h, uint32_t period)
 {
     if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
@@ -495,6 +557,7 @@ extern "C" int mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, doub
 {
     if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
     if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;
     HIP_TRY(hipStreamSynchronize(h->stream));
     uint64_t from = h->timing_base;
     if (h->runs - from > TIMING_RING) from = h->runs - TIMING_RING;
@@ -506,7 +569,7 @@ extern "C" int mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, doub
         hipEvent_t *ev = &h->ev[4 * (r % TIMING_RING)];
         float a = 0, b = 0;
         HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIP_TRY(hipEventElapsedTime(&b, ev[0], ev[3]));
+        HIP_TRY(hipEventElapsedTime(&b, ev[0], h->total_from_k1[r % TIMING_RING] ? ev[1] : ev[3]));
         k += a; t += b;
     }
     if (runs) *runs = n_timed;
@@ -548,6 +611,7 @@ static int fetch_internal(mpc_hip_handle *h, mpc_result *h_results, uint32_t n_p
     if (!h->ran) { mpc_set_err("fetch_results: nothing has run since the last upload"); return MPC_ERR_INVALID; }
     if (n_problems != h->n_probs) { mpc_set_err("fetch_results: n_problems differs from the uploaded batch"); return MPC_ERR_INVALID; }
     if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;
     HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results, sizeof(DevResult) * n_problems, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     float k1 = 0, total = 0;
@@ -575,6 +639,8 @@ extern "C" int mpc_hip_fetch_results(mpc_hip_handle *h, mpc_result *h_results, u
 extern "C" int mpc_hip_device_winners(mpc_hip_handle *h, uint64_t **d_winners)
 {
     if (!h || !d_winners) { mpc_set_err("device_winners: NULL argument"); return MPC_ERR_INVALID; }
+    if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;
     *d_winners = h->d_winners;
     return MPC_OK;
 }
@@ -590,6 +656,7 @@ extern "C" int mpc_hip_copy_winners(mpc_hip_handle *h, uint64_t *d_dst)
 {
     if (!h || !d_dst || h->n_probs == 0) { mpc_set_err("copy_winners: NULL argument or nothing uploaded"); return MPC_ERR_INVALID; }
     if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;
     HIP_TRY(hipMemcpyAsync(d_dst, h->d_winners, sizeof(uint64_t) * 2 * h->n_probs, hipMemcpyDeviceToDevice, h->stream));
     return MPC_OK;
 }

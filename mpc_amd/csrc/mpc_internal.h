@@ -69,6 +69,33 @@ struct LevelPtrs {
     uint32_t *parent, *count, *offset;
 };
 
+/* everything K2 needs, as one record: the standalone kernel takes it as its argument, and a rollout launch that also
+ * finishes the PREVIOUS solve (FUSE, below) carries that solve's record next to its own arguments */
+struct FinishArgs {
+    const DevProblem *probs;
+    const float *rud, *thr;
+    uint64_t first, count;
+    int selection, fast, uniform;
+    double refine_rel;
+    uint32_t nblk, k1_block;
+    const uint64_t *pkey, *pord;
+    const uint32_t *pcnt;
+    const double *keys;
+    double *snap_base;
+    int snap_depth;
+    uint64_t *winners, *sink;
+    DevResult *results;
+};
+/* what K1 writes and K2 reads, twice (mpc_hip_set_pipeline): half 0's workgroup triples are h->d_pkey/d_pord/d_pcnt,
+ * shared with the tree search */
+struct WorkMem {
+    double *d_keys = nullptr; size_t cap_keys = 0;
+    double *d_snap = nullptr; size_t cap_snap = 0;
+    uint64_t *d_pkey = nullptr; size_t cap_pkey = 0;
+    uint64_t *d_pord = nullptr; size_t cap_pord = 0;
+    uint32_t *d_pcnt = nullptr; size_t cap_pcnt = 0;
+};
+
 struct mpc_hip_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -89,11 +116,14 @@ struct mpc_hip_handle {
     uint32_t *d_list_count = nullptr;                           /* per-problem scratch word (tree trace cursor) */
     uint64_t *d_pkey = nullptr, *d_pord = nullptr;              /* K1 workgroup triples */
     uint32_t *d_pcnt = nullptr;
-    double *d_snap = nullptr;                                   /* per-level snapshots */
-    size_t cap_snap = 0;
     size_t cap_partials = 0;
-    double *d_keys = nullptr;
-    size_t cap_keys = 0;
+    WorkMem wm[2];                                              /* keys, snapshots (and half 1's triples) */
+    /* deferred finish (mpc_hip.hip) */
+    bool pipeline = false, pending = false, pend_seeded = false, pend_timed = false;
+    FinishArgs pend{};
+    uint32_t pend_n_probs = 0, pend_slot = 0;
+    int pend_half = 0;
+    std::vector<uint8_t> total_from_k1;
     double *d_controls = nullptr;                               /* 2 * MPC_MAX_DEPTH, mpc_hip_rollout */
     void *d_static_scratch = nullptr;                           /* this device's copy of scratch[] (mpc_hip.hip), not owned */
 
@@ -122,6 +152,7 @@ struct mpc_hip_handle {
 int mpc_use_device(const mpc_hip_handle *h);
 int mpc_ensure_problem_capacity(mpc_hip_handle *h, uint32_t n);
 int mpc_ensure_partials(mpc_hip_handle *h, size_t n);
+int mpc_flush_pending(mpc_hip_handle *h);
 int mpc_check_problem(const mpc_problem *p, int precision);
 void mpc_pack_problem(const mpc_problem *p, uint64_t seed, const mpc::Model &model, DevProblem *d);
 const mpc::Model &mpc_model_of(const mpc_hip_handle *h, uint32_t problem);

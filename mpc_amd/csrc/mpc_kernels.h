@@ -225,98 +225,30 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
-/* K1: rollout + cost + block argmin                                                                       */
-/* ------------------------------------------------------------------------------------------------------ */
-template <int PREC, bool SEEDED, bool UNIFORM>
-__global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restrict__ probs,
-                                                      const float *__restrict__ rud, const float *__restrict__ thr,
-                                                      uint64_t first, uint64_t count, int selection, double refine_rel,
-                                                      double *__restrict__ cost_last, double *__restrict__ cost_cum,
-                                                      double *__restrict__ keys, double *__restrict__ snap_base,
-                                                      int snap_depth, uint64_t *__restrict__ pkey,
-                                                      uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const DevProblem &P = probs[blockIdx.y];
-    double *cpL = lds;
-    double *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
-    uint64_t *red = (uint64_t *)(subL + MPC_MAX_SUBSTEPS * SUB_STRIDE);       /* 8 words argmin + 2 words (+ 2 pad) */
-    float *ctlL = (float *)(red + 12);                                         /* [depth][2][blockDim] (explicit sets) */
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    /* prologue: every global load of the workgroup is issued before the first wait (problem record, then controls;
-     * explicit sets hold one problem, whose depth is snap_depth) */
-    StagedProblem staged;
-    float ca[CTL_CHUNK], cb[CTL_CHUNK];
-    const uint64_t ic = i < count ? i : count - 1;          /* count >= 1 (host) */
-    stage_problem_load(P, staged);
-    if (!SEEDED) ctl_chunk_load(rud, thr, count, ic, snap_depth, 0, ca, cb);            /* snap_depth >= 1 (host) */
-    /* all global loads first, then the LDS writes (left alone, the scheduler interleaves them and the first wait
-     * comes with half of the loads still to be issued): 0x020 = VMEM reads, 0x200 = DS writes */
-    __builtin_amdgcn_sched_group_barrier(0x020, STAGE_TRIPS + 2 * CTL_CHUNK, 0);
-    __builtin_amdgcn_sched_group_barrier(0x200, STAGE_TRIPS + 2 * CTL_CHUNK, 0);
-    stage_problem_store(staged, cpL);
-    if (!SEEDED) {
-        ctl_chunk_store(ctlL, snap_depth, 0, ca, cb);
-        for (int base = CTL_CHUNK; base < snap_depth; base += CTL_CHUNK) {       /* deeper than one chunk: a round trip each */
-            ctl_chunk_load(rud, thr, count, ic, snap_depth, base, ca, cb);
-            ctl_chunk_store(ctlL, snap_depth, base, ca, cb);
-        }
-    }
-    uint64_t k = ~0ull, o = ~0ull;
-    double mykey = __longlong_as_double((long long)KEY_INF);
-    if (i < count) {
-        const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
-                              SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x};
-        const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count : nullptr,
-                                       count, snap_depth, i);
-        double last, cum;
-        if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
-        else eval_fast<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
-        const uint64_t at = (uint64_t)blockIdx.y * count + i;
-        if (cost_last) cost_last[at] = last;
-        if (cost_cum) cost_cum[at] = cum;
-        k = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
-        o = first + i;
-        mykey = __longlong_as_double((long long)k);
-        keys[at] = mykey;
-    }
-    block_argmin(k, o, red);
-    /* how many of this workgroup's candidates lie within refine_rel of ITS minimum (a superset test for the
-     * global one): 1 in all but freak cases, which lets K2 build the refine list from the triples alone */
-    uint32_t *cnt = (uint32_t *)(red + 9);
-    if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
-    __syncthreads();
-    const double m = __longlong_as_double((long long)red[8]);
-    const bool near = (i < count) && (mykey <= m + m * refine_rel);
-    const uint32_t wave_n = (uint32_t)__popcll(__ballot(near));
-    if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint64_t b = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
-        pkey[b] = k; pord[b] = o; pcnt[b] = *cnt;
-    }
-}
-
-/* ------------------------------------------------------------------------------------------------------ */
 /* K2: per problem -- reduce, refine list, strict decision among near-ties, the winner's trajectory        */
 /* ------------------------------------------------------------------------------------------------------ */
-template <bool SEEDED>
-__global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restrict__ probs,
-                                                     const float *__restrict__ rud, const float *__restrict__ thr,
-                                                     uint64_t first, uint64_t count, int selection, int fast,
-                                                     int uniform, double refine_rel, uint32_t nblk, uint32_t k1_block,
-                                                     const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
-                                                     const uint32_t *__restrict__ pcnt, const double *__restrict__ keys,
-                                                     double *__restrict__ snap_base, int snap_depth,
-                                                     uint64_t *__restrict__ winners, uint64_t *__restrict__ sink,
-                                                     DevResult *__restrict__ results)
+#define FINISH_LDS_WORDS 16          /* uint64 words of small shared state: red[8], s_win[2], s_n */
+
+/* p = problem; lds = cpL (subL follows, as stage_problem_store lays them out); s_list[LIST_CAP]; small[FINISH_LDS_WORDS].
+ * Works for any workgroup size that is a multiple of 64 and at least MPC_MAX_DEPTH lanes. */
+template <bool SEEDED, uint32_t FIN_U>
+__device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds, uint64_t *s_list, uint64_t *small)
 {
-    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
-    __shared__ uint64_t s_list[LIST_CAP];
-    __shared__ uint64_t red[8];
-    __shared__ uint64_t s_win[2];
-    __shared__ uint32_t s_n;
-    const uint32_t p = blockIdx.x;
+    const DevProblem *__restrict__ probs = A.probs;
+    const float *__restrict__ rud = A.rud, *__restrict__ thr = A.thr;
+    const uint64_t first = A.first, count = A.count;
+    const int selection = A.selection, fast = A.fast, uniform = A.uniform;
+    const double refine_rel = A.refine_rel;
+    const uint32_t nblk = A.nblk, k1_block = A.k1_block;
+    const uint64_t *__restrict__ pkey = A.pkey, *__restrict__ pord = A.pord;
+    const uint32_t *__restrict__ pcnt = A.pcnt;
+    const double *__restrict__ keys = A.keys;
+    double *__restrict__ snap_base = A.snap_base;
+    const int snap_depth = A.snap_depth;
+    uint64_t *__restrict__ winners = A.winners, *__restrict__ sink = A.sink;
+    DevResult *__restrict__ results = A.results;
+    uint64_t *red = small, *s_win = small + 8;
+    uint32_t &s_n = *(uint32_t *)(small + 10);
     const DevProblem &P = probs[p];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (threadIdx.x == 0) s_n = 0;
@@ -328,7 +260,6 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
     /* 1. the workgroup triples' minimum (lowest ordinal among equal keys).  K2 is a chain of memory latencies, so
      *    every trip keeps FIN_U triples per thread in flight (indices clamped, not predicated: a repeated triple
      *    does not change a minimum), and the first trip's loads travel together with the problem record's. */
-    constexpr uint32_t FIN_U = 4;
     uint64_t kk[FIN_U], oo[FIN_U];
     uint32_t cc[FIN_U];
 #pragma unroll
@@ -457,6 +388,104 @@ __global__ __launch_bounds__(256) void finish_kernel(const DevProblem *__restric
         R.refined = n > 1 ? n : 0; R.overflow = overflow;
         winners[2 * p] = kb; winners[2 * p + 1] = win;
         if (sink) { sink[2 * p] = kb; sink[2 * p + 1] = win; }
+    }
+}
+
+template <bool SEEDED>
+__global__ __launch_bounds__(256) void finish_kernel(const FinishArgs A)
+{
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ uint64_t s_list[LIST_CAP];
+    __shared__ uint64_t small[FINISH_LDS_WORDS];
+    finish_body<SEEDED, 4>(A, blockIdx.x, lds, s_list, small);
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* K1: rollout + cost + block argmin                                                                       */
+/* ------------------------------------------------------------------------------------------------------ */
+/* FUSE: the launch carries one more workgroup per problem (the last of each grid row) that is not a rollout
+ * workgroup but K2 of the PREVIOUS solve -- its arguments in `prev`, its data in the other half of the handle's
+ * double-buffered working memory.  That finish is a chain of memory round trips on one workgroup (~6 us as a kernel of
+ * its own, plus a dispatch boundary); here it runs beside a thousand rollout workgroups that do not wait for it, so a
+ * stream of solves costs ONE dispatch each.  (Round 1 tried the other fusion -- the LAST-arriving workgroup of solve n
+ * finishes solve n -- which serialises the same chain behind the rollout: slower than two kernels.)  Its LDS comes out
+ * of the dynamic allocation: the problem staging area it shares by layout, the near-tie list sits where a rollout
+ * workgroup keeps its controls (the host sizes the allocation for both). */
+template <int PREC, bool SEEDED, bool UNIFORM, bool FUSE = false>
+__global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restrict__ probs,
+                                                      const float *__restrict__ rud, const float *__restrict__ thr,
+                                                      uint64_t first, uint64_t count, int selection, double refine_rel,
+                                                      double *__restrict__ cost_last, double *__restrict__ cost_cum,
+                                                      double *__restrict__ keys, double *__restrict__ snap_base,
+                                                      int snap_depth, uint64_t *__restrict__ pkey,
+                                                      uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt,
+                                                      const FinishArgs prev)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *cpL = lds;
+    double *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    uint64_t *red = (uint64_t *)(subL + MPC_MAX_SUBSTEPS * SUB_STRIDE);       /* 8 words argmin + 2 words (+ 2 pad) */
+    float *ctlL = (float *)(red + 12);                                         /* [depth][2][blockDim] (explicit sets) */
+    const uint32_t n_rollout_blocks = FUSE ? gridDim.x - 1 : gridDim.x;
+    if (FUSE && blockIdx.x == n_rollout_blocks) {                              /* uniform per workgroup */
+        /* FINISH_LDS_WORDS (16) > the 12 words at `red`: the small state goes behind the list */
+        uint64_t *s_list = (uint64_t *)ctlL;
+        finish_body<SEEDED, 16>(prev, blockIdx.y, lds, s_list, s_list + LIST_CAP);
+        return;
+    }
+    const DevProblem &P = probs[blockIdx.y];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    /* prologue: every global load of the workgroup is issued before the first wait (problem record, then controls;
+     * explicit sets hold one problem, whose depth is snap_depth) */
+    StagedProblem staged;
+    float ca[CTL_CHUNK], cb[CTL_CHUNK];
+    const uint64_t ic = i < count ? i : count - 1;          /* count >= 1 (host) */
+    stage_problem_load(P, staged);
+    if (!SEEDED) ctl_chunk_load(rud, thr, count, ic, snap_depth, 0, ca, cb);            /* snap_depth >= 1 (host) */
+    /* all global loads first, then the LDS writes (left alone, the scheduler interleaves them and the first wait
+     * comes with half of the loads still to be issued): 0x020 = VMEM reads, 0x200 = DS writes */
+    __builtin_amdgcn_sched_group_barrier(0x020, STAGE_TRIPS + 2 * CTL_CHUNK, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, STAGE_TRIPS + 2 * CTL_CHUNK, 0);
+    stage_problem_store(staged, cpL);
+    if (!SEEDED) {
+        ctl_chunk_store(ctlL, snap_depth, 0, ca, cb);
+        for (int base = CTL_CHUNK; base < snap_depth; base += CTL_CHUNK) {       /* deeper than one chunk: a round trip each */
+            ctl_chunk_load(rud, thr, count, ic, snap_depth, base, ca, cb);
+            ctl_chunk_store(ctlL, snap_depth, base, ca, cb);
+        }
+    }
+    uint64_t k = ~0ull, o = ~0ull;
+    double mykey = __longlong_as_double((long long)KEY_INF);
+    if (i < count) {
+        const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
+                              SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x};
+        const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count : nullptr,
+                                       count, snap_depth, i);
+        double last, cum;
+        if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
+        else eval_fast<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
+        const uint64_t at = (uint64_t)blockIdx.y * count + i;
+        if (cost_last) cost_last[at] = last;
+        if (cost_cum) cost_cum[at] = cum;
+        k = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
+        o = first + i;
+        mykey = __longlong_as_double((long long)k);
+        keys[at] = mykey;
+    }
+    block_argmin(k, o, red);
+    /* how many of this workgroup's candidates lie within refine_rel of ITS minimum (a superset test for the
+     * global one): 1 in all but freak cases, which lets K2 build the refine list from the triples alone */
+    uint32_t *cnt = (uint32_t *)(red + 9);
+    if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
+    __syncthreads();
+    const double m = __longlong_as_double((long long)red[8]);
+    const bool near = (i < count) && (mykey <= m + m * refine_rel);
+    const uint32_t wave_n = (uint32_t)__popcll(__ballot(near));
+    if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t b = (uint64_t)blockIdx.y * n_rollout_blocks + blockIdx.x;
+        pkey[b] = k; pord[b] = o; pcnt[b] = *cnt;
     }
 }
 

@@ -150,6 +150,7 @@ class ShardCombiner:
 
     def _close_batch(self):
         r = self.slot
+        self.solver.flush()                  # a deferred finish (mpc_hip_set_pipeline) deposits the batch's last row now
         if self.collective:
             self.work[r] = dist.all_gather_into_tensor(self.gathered[r], self.win[r], group=self.group, async_op=True)
         self.stage[r] = 1

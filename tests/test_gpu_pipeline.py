@@ -1,0 +1,108 @@
+"""mpc_hip_set_pipeline: a stream of solves whose finish kernels ride in the NEXT solve's rollout launch returns, bit
+for bit, what the two-kernel form returns -- winners deposited through the sink, results fetched at the end or in
+between, runs that cannot fuse (strict precision, reference-native schedule, another candidate source) mixed in."""
+import numpy as np
+import pytest
+
+import mpc_amd as M
+from mpc_amd import workloads as W
+from helpers import traj_array
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _stream_of_solves(solver, pipeline, plan):
+    """plan: list of (kind, arg...) steps; returns every observable, in order"""
+    torch = _torch()
+    solver.set_pipeline(pipeline)
+    seen = []
+    p = W.config2_problem(depth=8)
+    p11 = M.make_problem((0.5, -0.5, 1.5, 1.8), W.config2_plan().checkpoints(W.T0, 6), M.substep_schedule(1.0),
+                         last=(0.1, 0.6), current=(0.2, -0.1))
+    n = 4096
+    rud, thr = W.seeded_controls(W.SEED + 5, 0, n, 8, p.last_rudder, p.last_throttle)
+    d_r = torch.tensor(rud.astype(np.float32), device="cuda").contiguous()
+    d_t = torch.tensor(thr.astype(np.float32), device="cuda").contiguous()
+    sinks = torch.full((len(plan), 2), -7, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    solver.upload([p], [W.SEED])
+    for k, step in enumerate(plan):
+        solver.set_winner_sink(sinks[k])
+        if step == "seeded":
+            solver.run_seeded(k * 1000, n, M.PREC_FAST)
+        elif step == "seeded_small":
+            solver.run_seeded(k * 1000, 777, M.PREC_FAST)
+        elif step == "strict":
+            solver.run_seeded(k * 1000, 2048, M.PREC_F64)
+        elif step == "explicit":
+            solver.run_candidates(d_r, d_t, n, M.PREC_FAST)
+        elif step == "cumulative":
+            solver.run_seeded(k * 1000, n, M.PREC_FAST, M.SELECT_CUMULATIVE)
+        elif step == "native":
+            solver.upload([p11], [W.SEED + k])
+            solver.run_seeded(0, n, M.PREC_FAST)
+        elif step == "reupload":
+            solver.upload([p], [W.SEED + k])
+            solver.run_seeded(0, n, M.PREC_FAST)
+        elif step == "fetch":
+            r = solver.fetch()[0]
+            seen.append(("fetch", r.best_ordinal, r.best_last, r.best_cumulative, traj_array(r).tobytes()))
+            solver.run_seeded(k * 1000, n, M.PREC_FAST)
+        else:
+            raise AssertionError(step)
+    solver.set_winner_sink(None)
+    r = solver.fetch()[0]
+    seen.append(("last", r.best_ordinal, r.best_last, r.best_cumulative, traj_array(r).tobytes()))
+    solver.synchronize()
+    seen.append(("sinks", sinks.cpu().numpy().tobytes()))
+    solver.set_pipeline(False)
+    return seen
+
+
+@pytest.mark.parametrize("plan", [
+    ["seeded"] * 6,
+    ["explicit"] * 5,
+    ["seeded", "seeded_small", "seeded", "cumulative", "seeded"],
+    ["seeded", "strict", "seeded", "explicit", "seeded", "native", "seeded", "reupload", "seeded"],
+    ["seeded", "fetch", "seeded", "fetch", "explicit", "explicit", "fetch"],
+])
+def test_deferred_finish_changes_no_result(plan):
+    solver = M.Solver(0)
+    try:
+        want = _stream_of_solves(solver, False, plan)
+        got = _stream_of_solves(solver, True, plan)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a == b, a[0]
+        sinks = np.frombuffer(want[-1][1], dtype=np.int64).reshape(-1, 2)
+        assert (sinks[:, 1] >= 0).all()                       # every run deposited its winners in ITS row
+    finally:
+        solver.close()
+
+
+def test_deferred_finish_on_a_fleet_and_with_timing():
+    solver = M.Solver(0)
+    try:
+        probs, seeds = W.fleet_problems(24, depth=10)
+        out = []
+        for pipeline in (False, True):
+            solver.set_pipeline(pipeline)
+            solver.set_timing(1)
+            solver.upload(probs, seeds)
+            solver.timing(reset=True)
+            for k in range(4):
+                solver.run_seeded(0, 1024 + 64 * k, M.PREC_FAST)
+            runs, k_ms, t_ms = solver.timing(reset=True)
+            assert runs == 4 and 0 < k_ms <= t_ms
+            res = solver.fetch()
+            out.append([(r.status, r.best_ordinal, r.best_last, traj_array(r).tobytes()) for r in res])
+        assert out[0] == out[1]
+        solver.set_timing(1)
+    finally:
+        solver.close()
