@@ -228,3 +228,97 @@ def test_the_first_level_beyond_the_storage_cap_is_the_final_one(solver):
         assert deep.levels == ref.levels == 7 and dl[6].n_leaves == 303370833
         assert (deep.best_ordinal, deep.best_last, deep.best_cumulative) == (ref.best_ordinal, ref.best_last, ref.best_cumulative)
         assert traj_array(deep).tobytes() == traj_array(ref).tobytes()
+
+
+def _control_sets(p, last_r, last_t):
+    """controller.cpp:121-146 in Python floats (the same IEEE operations): the control set of a node from its incoming control"""
+    tol = p.tolerance
+    rud = [p.min_rudder, p.mid_rudder, p.max_rudder]
+    lo, hi = last_r - p.rudder_granularity, last_r + p.rudder_granularity
+    if p.min_rudder + tol < lo and abs(p.mid_rudder - lo) > tol:
+        rud.append(lo)
+    if abs(p.mid_rudder - hi) > tol and p.max_rudder > hi + tol:
+        rud.append(hi)
+    if abs(p.min_rudder - last_r) > tol and abs(p.mid_rudder - last_r) > tol and abs(p.max_rudder - last_r) > tol:
+        rud.append(last_r)
+    thr = [p.min_throttle, p.max_throttle]
+    lo, hi = last_t - p.throttle_granularity, last_t + p.throttle_granularity
+    if p.min_throttle + tol < lo:
+        thr.append(lo)
+    if p.max_throttle > hi + tol:
+        thr.append(hi)
+    if abs(p.min_throttle - last_t) > tol and abs(p.max_throttle - last_t) > tol:
+        thr.append(last_t)
+    return rud, thr
+
+
+def _leaf_counts(p, depth):
+    """leaves per level without simulating anything: the tree's shape depends on the controls alone"""
+    states = {(p.last_rudder, p.last_throttle): 1}
+    counts = []
+    for _ in range(depth):
+        nxt = {}
+        for (r, t), mult in states.items():
+            rud, thr = _control_sets(p, r, t)
+            for tt in thr:
+                for rr in rud:
+                    nxt[(rr, tt)] = nxt.get((rr, tt), 0) + mult
+        states = nxt
+        counts.append(sum(states.values()))
+    return counts
+
+
+def test_depth_8_as_the_8_shards_of_a_node(solver):
+    """The reference's deepening loop has no depth cap but its deadline (controller.cpp:80,101).  Depth 8 -- 5.2e9
+    leaves, 5.7e10 simulate substeps -- is what a node's 8 GPUs buy the production path: each shard's leaves fit 32-bit
+    local ordinals, the global DFS ordinal is 64-bit.  The 8 shards run one after the other on this GPU.  Checked: per
+    level the shards' leaf counts sum to the count recursion of the control sets; levels 1-4 equal the oracle's DFS;
+    the winner's path re-scored by the oracle's rollout matches the returned trajectory to 1e-12; no sampled leaf
+    (random valid control sequences, scored by the oracle) beats the winner."""
+    import torch
+    from mpc_amd.distributed import tree_levels_tensor, combine_tree_levels
+    depth, n_shards, split = 8, 8, 3
+    p, _plan = W.config1_problem(depth=depth)
+    assert p.depth == depth
+    shards = [solver.solve_tree(p, depth, precision=M.PREC_FAST, split_level=split, shard=s, n_shards=n_shards)
+              for s in range(n_shards)]
+    assert all(r.status == 0 and r.levels == depth for r, _ in shards)
+    combined = combine_tree_levels(torch.stack([tree_levels_tensor(lv, depth) for _, lv in shards]), split)
+    want_counts = _leaf_counts(p, depth)
+    assert [c[0] for c in combined] == want_counts and want_counts[-1] == 5172889071 > 2 ** 32
+    # the shallow levels against the oracle's own DFS
+    it, traj, olev, _ = _oracle_tree(p, 4)
+    for l in range(4):
+        assert (combined[l][0], combined[l][1]) == (olev[l].n_leaves, olev[l].best_leaf), l
+        assert combined[l][2] == int(np.float64(olev[l].best_score).view(np.int64)) or \
+            rel_err(np.int64(combined[l][2]).view(np.float64), olev[l].best_score) <= TOL
+    total, ordinal, bits, owner = combined[-1]
+    assert ordinal >= 0 and total == want_counts[-1]
+    res = shards[owner][0]
+    got = traj_array(res)
+    assert rel_err(res.best_last, np.int64(bits).view(np.float64)) == 0.0
+    # the winner's path through the oracle
+    cfg, veh, cps, sub = oracle_args(p)
+    o = O.rollout(cfg, veh, cps, depth, sub, got[1:, 7], got[1:, 8])
+    for l in range(depth + 1):
+        want = [o[l].v.s.x, o[l].v.s.y, o[l].v.s.heading, o[l].v.s.speed, o[l].v.rpm]
+        assert rel_err(got[l, :5], want).max() <= TOL, l
+        assert rel_err(got[l, 9], o[l].score) <= TOL
+    best_last = o[depth].score - o[depth - 1].score
+    assert rel_err(res.best_last, best_last) <= 1e-10                 # a difference of two cumulative scores
+    # the path is a valid one: every control comes from its parent's control set
+    lr, lt = p.last_rudder, p.last_throttle
+    for l in range(1, depth + 1):
+        rud, thr = _control_sets(p, lr, lt)
+        assert got[l, 7] in rud and got[l, 8] in thr, l
+        lr, lt = got[l, 7], got[l, 8]
+    # sampled leaves: none has a smaller last-step score
+    rng = np.random.RandomState(8)
+    for _ in range(400):
+        lr, lt, rs, ts = p.last_rudder, p.last_throttle, [], []
+        for l in range(depth):
+            rud, thr = _control_sets(p, lr, lt)
+            lr, lt = rud[rng.randint(len(rud))], thr[rng.randint(len(thr))]
+            rs.append(lr); ts.append(lt)
+        s = O.rollout(cfg, veh, cps, depth, sub, rs, ts)
+        assert s[depth].score - s[depth - 1].score >= res.best_last * (1 - 1e-10)
