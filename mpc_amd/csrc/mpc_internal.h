@@ -147,6 +147,7 @@ struct mpc_hip_handle {
     LevelPtrs *d_level_ptrs = nullptr;                           /* [MPC_MAX_DEPTH + 2], fast-mode path walks */
     std::vector<LevelPtrs> h_level_ptrs;                         /* its host image (copies are asynchronous) */
     uint64_t *h_pair = nullptr;                                  /* pinned, 4 uint64 */
+    uint64_t *d_tree_meta = nullptr, *h_tree_meta = nullptr;     /* per-level records of the blind shallow levels (pinned host copy) */
 };
 
 int mpc_use_device(const mpc_hip_handle *h);

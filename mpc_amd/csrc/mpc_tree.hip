@@ -77,13 +77,22 @@ static LevelPtrs ptrs(const TreeLevelBuf &b)
 
 /* Node records.  strict: x y h v rpm cmg sog.  fast (MPC_PREC_FAST): x, y through the water, h = sin(heading),
  * cmg = cos(heading), v, rpm, sog = the last substep's v*dt -- the FastVeh of mpc_model.h in the same arrays. */
-__global__ void root_kernel(const DevProblem *__restrict__ probs, LevelPtrs L, int fast)
+/* meta (optional; the blind shallow levels, below): also the root's child count and offsets, so that level 1 can be
+ * expanded without a scan launch: meta[l * TREE_META + 0] = nodes of level l */
+#define TREE_META 8              /* uint64 per level: nodes, winner key, winner ordinal, cum bits, last bits, overflow, clock, - */
+__global__ void root_kernel(const DevProblem *__restrict__ probs, LevelPtrs L, int fast, uint32_t *__restrict__ bpar,
+                            uint64_t *__restrict__ meta)
 {
     if (threadIdx.x || blockIdx.x) return;
     const DevProblem &P = probs[0];
     L.x[0] = P.sx; L.y[0] = P.sy; L.h[0] = fast ? sin(P.sh) : P.sh; L.v[0] = P.sv; L.rpm[0] = P.srpm;
     L.cmg[0] = fast ? cos(P.sh) : 0; L.sog[0] = 0; L.last_r[0] = P.last_r; L.last_t[0] = P.last_t; L.cum[0] = 0; L.last_score[0] = 0;
     L.parent[0] = 0;
+    if (meta) {
+        const uint32_t c = control_count(P, P.last_r, P.last_t);
+        L.count[0] = c; L.offset[0] = 0; L.offset[1] = c; bpar[0] = 0;
+        meta[0] = 1; meta[TREE_META] = c;
+    }
 }
 
 __global__ __launch_bounds__(256) void count_kernel(const DevProblem *__restrict__ probs, LevelPtrs L, uint32_t n)
@@ -238,18 +247,26 @@ __device__ inline uint32_t window_parent(const uint32_t *win, uint32_t par0, uin
     return par0 + lo;
 }
 
+/* meta_parent != nullptr (the blind shallow levels): n_parent / n_child are upper bounds the grid was sized for; the
+ * real counts are read from the device (meta_parent[0], meta_parent[TREE_META]) and surplus workgroups leave. */
 template <bool STORE>
 __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                      const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
-                                                     uint32_t tpb, uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord)
+                                                     uint32_t tpb, uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
+                                                     const uint64_t *__restrict__ meta_parent)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[8];
     __shared__ uint32_t win[2][PARENT_WINDOW];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
     const uint32_t n_tiles = (n_child + 255) / 256;
     const uint32_t tile0 = blockIdx.x * tpb;
+    if (tile0 >= n_tiles) {                                          /* uniform: a workgroup beyond the level */
+        if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; }
+        return;
+    }
     uint32_t par0 = bpar[tile0];                                     /* the parent of the tile's first child (scan_apply_kernel) */
     if (threadIdx.x < PARENT_WINDOW) win[0][threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
     stage_problem(P, cpL, subL);                                     /* ends with a barrier */
@@ -324,15 +341,20 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                                                           const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
                                                           double refine_rel, uint32_t tpb,
                                                           uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
-                                                          uint32_t *__restrict__ pcnt)
+                                                          uint32_t *__restrict__ pcnt, const uint64_t *__restrict__ meta_parent)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
     __shared__ uint32_t win[2][PARENT_WINDOW];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
     const uint32_t n_tiles = (n_child + 255) / 256;
     const uint32_t tile0 = blockIdx.x * tpb;
+    if (tile0 >= n_tiles) {
+        if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; pcnt[blockIdx.x] = 0; }
+        return;
+    }
     uint32_t par0 = bpar[tile0];
     if (threadIdx.x < PARENT_WINDOW) win[0][threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
     stage_problem(P, cpL, subL);
@@ -422,18 +444,25 @@ __device__ inline void strict_path(const DevProblem &P, const double *cpL, const
 /* one workgroup per level: fast minimum -> near-tie list -> strict decision.  out[0..3] = strict key bits, leaf
  * ordinal, strict cumulative and last-step score bits; out[4] = 1 if more than LIST_CAP leaves tie (the caller then
  * repeats the search with the strict expansion). */
-__global__ __launch_bounds__(256) void tree_finish_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
-                                                          int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
-                                                          const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
-                                                          const uint32_t *__restrict__ pcnt, uint32_t nblk,
-                                                          uint64_t *__restrict__ out)
+struct TreeFinishLds {
+    double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    uint64_t s_list[LIST_CAP];
+    uint64_t red[8];
+    uint64_t s_win[2];
+    uint32_t s_blocks[256];
+    uint32_t s_n, s_nb;
+};
+
+__device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
+                                        int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
+                                        const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
+                                        const uint32_t *__restrict__ pcnt, uint32_t nblk,
+                                        uint64_t *__restrict__ out, TreeFinishLds &S)
 {
-    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
-    __shared__ uint64_t s_list[LIST_CAP];
-    __shared__ uint32_t s_blocks[256];
-    __shared__ uint64_t red[8];
-    __shared__ uint64_t s_win[2];
-    __shared__ uint32_t s_n, s_nb;
+    double *lds = S.lds;
+    uint64_t *s_list = S.s_list, *red = S.red, *s_win = S.s_win;
+    uint32_t *s_blocks = S.s_blocks;
+    uint32_t &s_n = S.s_n, &s_nb = S.s_nb;
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (threadIdx.x == 0) { s_n = 0; s_nb = 0; }
@@ -501,6 +530,86 @@ __global__ __launch_bounds__(256) void tree_finish_kernel(const DevProblem *__re
     }
 }
 
+__global__ __launch_bounds__(256) void tree_finish_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
+                                                          int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
+                                                          const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
+                                                          const uint32_t *__restrict__ pcnt, uint32_t nblk,
+                                                          uint64_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) TreeFinishLds S;
+    tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, out, S);
+}
+
+/* ---- the blind shallow levels --------------------------------------------------------------------------------
+ * While a level cannot have more than BLIND_MAX_NODES nodes whatever the problem (30^l: levels 1-4), the host does not
+ * need its size to launch it: buffers and grids are sized for the bound, the kernels read the real counts from the
+ * device (meta[]), surplus workgroups leave, and ONE read-back after the last blind level returns every level's
+ * size and winner.  Per level two launches -- expand, and this one, which is the level's reduction (strict: + the
+ * record of an unstored level's winner and its scores; fast: tree_finish_body) followed by the count + exclusive scan
+ * of the new level for the next expansion -- instead of seven and two host round trips. */
+#define BLIND_MAX_NODES (1u << 20)
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void tree_post_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
+                                                        int L, int stored, double refine_rel, uint32_t tpb,
+                                                        const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
+                                                        const uint32_t *__restrict__ pcnt, uint64_t *__restrict__ out,
+                                                        uint64_t *__restrict__ meta, int do_scan, uint32_t *__restrict__ bpar)
+{
+    __shared__ __attribute__((aligned(16))) TreeFinishLds S;
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    const DevProblem &P = probs[0];
+    const uint32_t n_parent = (uint32_t)meta[L * TREE_META], n_child = (uint32_t)meta[(L + 1) * TREE_META];
+    const uint32_t n_tiles = (n_child + 255) / 256, nblk = (n_tiles + tpb - 1) / tpb;
+    const LevelPtrs A = levels[L], B = levels[L + 1];
+    if (FAST) {
+        tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, out, S);
+    } else {
+        stage_problem(P, S.lds, S.lds + MPC_MAX_DEPTH * CP_STRIDE);
+        uint64_t k = ~0ull, o = ~0ull;
+        for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
+        block_argmin(k, o, S.red);
+        if (threadIdx.x == 0) {
+            uint64_t cum = KEY_INF, last = KEY_INF;
+            if (o != ~0ull) {
+                uint32_t at = (uint32_t)o;
+                if (!stored) {                                   /* leaf_record_kernel: the winner's record into slot 0 */
+                    const uint32_t par = find_parent(A.offset, n_parent, (uint32_t)o);
+                    store_child(B, 0, make_child(P, S.lds, S.lds + MPC_MAX_DEPTH * CP_STRIDE, A, par, (uint32_t)o - A.offset[par], L));
+                    __threadfence();
+                    at = 0;
+                }
+                cum = (uint64_t)__double_as_longlong(B.cum[at]); last = (uint64_t)__double_as_longlong(B.last_score[at]);
+            }
+            out[0] = k; out[1] = o; out[2] = cum; out[3] = last; out[4] = 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t *m = meta + (L + 1) * TREE_META;
+        m[1] = out[0]; m[2] = out[1]; m[3] = out[2]; m[4] = out[3]; m[5] = FAST ? out[4] : 0;
+        m[6] = (uint64_t)wall_clock64();
+    }
+    if (!do_scan) return;
+    /* the new level as parents: children per node (controller.cpp:121-146) and their exclusive scan, one workgroup */
+    const uint32_t n = n_child, ipt = (n + SCAN_BLOCK - 1) / SCAN_BLOCK, lo = threadIdx.x * ipt;
+    uint32_t sum = 0;
+    for (uint32_t j = lo; j < min(lo + ipt, n); j++) {
+        const uint32_t c = control_count(P, B.last_r[j], B.last_t[j]);
+        B.count[j] = c; sum += c;
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, sh, total);
+    for (uint32_t j = lo; j < min(lo + ipt, n); j++) {
+        const uint32_t c = B.count[j];
+        B.offset[j] = run;
+        const uint64_t q = ((uint64_t)run + 255) >> 8;
+        if ((q << 8) < (uint64_t)run + c) bpar[q] = j;
+        run += c;
+    }
+    if (threadIdx.x == 0) { B.offset[n] = total; meta[(L + 2) * TREE_META] = total; }
+}
+
 /* the winner's trajectory: the strict model along its path (fast mode's replacement for the trace kernels) */
 __global__ __launch_bounds__(64) void path_trace_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
                                                         int L, uint32_t n_parent, uint32_t leaf, DevResult *__restrict__ results)
@@ -556,6 +665,24 @@ __global__ void trace_kernel(LevelPtrs L, int l, int depth, uint32_t leaf, uint3
     *cursor = L.parent[i];
 }
 
+/* all levels in one launch (the blind path): leaf view by value (a sliced level is looked up unsliced, see the host) */
+__global__ void trace_all_kernel(const LevelPtrs *__restrict__ levels, LevelPtrs leaf_level, int depth, uint32_t leaf,
+                                 uint32_t leaf_slot, DevResult *__restrict__ results)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    DevResult &R = results[0];
+    uint32_t i = leaf_slot;
+    for (int l = depth; l >= 0; l--) {
+        const LevelPtrs L = (l == depth) ? leaf_level : levels[l];
+        R.traj[l] = mpc_level_state{L.x[i], L.y[i], L.h[i], L.v[i], L.rpm[i], L.cmg[i], L.sog[i], L.last_r[i], L.last_t[i], L.cum[i]};
+        if (l == depth) {
+            R.best_last = L.last_score[i]; R.best_cum = L.cum[i]; R.key_bits = key_of(L.last_score[i]);
+            R.ordinal = leaf; R.refined = 0; R.overflow = 0;
+        }
+        i = L.parent[i];
+    }
+}
+
 /* ---- host ------------------------------------------------------------------------------------------------------ */
 static void free_level(TreeLevelBuf &b)
 {
@@ -572,6 +699,8 @@ void mpc_tree_free(mpc_hip_handle *h)
     (void)hipFree(h->d_scan_tmp); h->d_scan_tmp = nullptr; h->cap_scan_tmp = 0;
     (void)hipFree(h->d_level_ptrs); h->d_level_ptrs = nullptr;
     (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
+    (void)hipFree(h->d_tree_meta); h->d_tree_meta = nullptr;
+    (void)hipHostFree(h->h_tree_meta); h->h_tree_meta = nullptr;
 }
 
 static int ensure_level(mpc_hip_handle *h, TreeLevelBuf &b, size_t n)
@@ -621,14 +750,126 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     HIP_TRY(hipEventRecord(ev[0], h->stream));
     if (int s = ensure_level(h, h->tree[0], 1)) return s;
     h->tree[0].n = 1;
-    hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]), (int)fast);
-    HIP_TRY(hipGetLastError());
     if (int s = publish_level(h, 0)) return s;
 
     int completed = 0;
     uint64_t best_leaf = 0, steps = 0, evaluated = 0;
-    bool leaf_stored = true, overflow = false;
-    for (int it = 0; it < max_levels; it++) {
+    bool leaf_stored = true, overflow = false, stop = false;
+    auto record_level = [&](int it, uint64_t nchild, const uint64_t *w, bool stored) {
+        completed = it + 1;
+        best_leaf = w[1];
+        leaf_stored = stored;
+        evaluated += nchild;
+        steps += nchild * (uint64_t)h_problem->n_substeps;
+        if (h_level_best) {
+            h_level_best[it].n_leaves = nchild;
+            h_level_best[it].best_leaf = w[1];
+            memcpy(&h_level_best[it].best_score, &w[3], sizeof(double));
+            memcpy(&h_level_best[it].best_cumulative, &w[2], sizeof(double));
+        }
+    };
+    /* every shard has expanded the split level in full; from there on this one keeps a contiguous slice of its nodes
+     * (DFS order is preserved within and across shards) */
+    auto slice_level = [&](int level, bool stored) -> int {
+        TreeLevelBuf &B = h->tree[level];
+        const uint64_t nchild = B.n;
+        if (!stored) { mpc_set_err("solve_tree_shard: split_level must be below max_levels"); return MPC_ERR_INVALID; }
+        if (nchild < n_shards) { mpc_set_err("solve_tree_shard: the split level has fewer nodes than shards"); return MPC_ERR_INVALID; }
+        const uint64_t base = nchild / n_shards, extra = nchild % n_shards;
+        B.first = (size_t)(shard * base + std::min<uint64_t>(shard, extra));
+        B.n = (size_t)(base + (shard < extra ? 1 : 0));
+        return publish_level(h, level);
+    };
+
+    /* ---- the blind shallow levels (tree_post_kernel): no host round trip until the last of them ---- */
+    int blind = 0;
+    {
+        const int lim = n_shards > 1 ? std::min(max_levels, split_level) : max_levels;
+        uint64_t bound = 1;
+        static const bool sync_levels = getenv("MPC_HIP_TREE_SYNC_LEVELS") != nullptr;     /* diagnostic: every level the long way */
+        while (!sync_levels && blind < lim && bound * 30 <= BLIND_MAX_NODES) { bound *= 30; blind++; }
+    }
+    if (now && now(now_ctx) >= end_time) blind = 0;                       /* the loop below breaks at once */
+    if (!h->d_tree_meta) {
+        HIP_TRY(hipMalloc(&h->d_tree_meta, sizeof(uint64_t) * TREE_META * (MPC_MAX_DEPTH + 2)));
+        HIP_TRY(hipHostMalloc(&h->h_tree_meta, sizeof(uint64_t) * TREE_META * (MPC_MAX_DEPTH + 2)));
+    }
+    if (blind > 0) {
+        uint64_t bound = 1;
+        for (int l = 1; l <= blind; l++) {
+            bound *= 30;
+            TreeLevelBuf &B = h->tree[l];
+            B.first = 0;
+            if (int s = ensure_level(h, B, l < max_levels ? bound : 1)) return s;
+            if (int s = publish_level(h, l)) return s;
+        }
+        const size_t nbound = (size_t)bound / 256 + 2;
+        if (nbound > h->cap_bpar) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
+            HIP_TRY(hipMalloc(&h->d_bpar, sizeof(uint32_t) * nbound));
+            h->cap_bpar = nbound;
+        }
+        if (int s = mpc_ensure_partials(h, (size_t)(bound + 255) / 256)) return s;
+    } else if (h->cap_bpar < 2) {
+        (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
+        HIP_TRY(hipMalloc(&h->d_bpar, sizeof(uint32_t) * 64));
+        h->cap_bpar = 64;
+    }
+    hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]), (int)fast, h->d_bpar,
+                       blind > 0 ? h->d_tree_meta : (uint64_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    if (blind > 0) {
+        uint64_t pb = 1;
+        for (int it = 0; it < blind; it++) {
+            const uint64_t cb = pb * 30;                                   /* <= 30 children per node (6 x 5) */
+            const uint32_t nblk = (uint32_t)((cb + 255) / 256);
+            const bool stored = it + 1 < max_levels;
+            const uint64_t *mp = h->d_tree_meta + (size_t)it * TREE_META;
+            TreeLevelBuf &A = h->tree[it], &B = h->tree[it + 1];
+            if (fast) {
+                if (stored) hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
+                                               (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp);
+                else hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
+                                        (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp);
+                hipLaunchKernelGGL(tree_post_kernel<true>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
+                                   (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_winners, h->d_tree_meta,
+                                   (int)(stored && it + 1 < blind), h->d_bpar);
+            } else {
+                if (stored) hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
+                                               (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, mp);
+                else hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
+                                        (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, mp);
+                hipLaunchKernelGGL(tree_post_kernel<false>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
+                                   0.0, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_winners, h->d_tree_meta,
+                                   (int)(stored && it + 1 < blind), h->d_bpar);
+            }
+            pb = cb;
+            if (!stored) { blind = it + 1; break; }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_tree_meta, h->d_tree_meta, sizeof(uint64_t) * TREE_META * (size_t)(blind + 1), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        /* deadline (controller.cpp:101-103): if the clock has passed end_time by now, the levels that completed before it
+         * still count -- each level's completion time is the caller's clock now minus the GPU's own (100 MHz) clock
+         * difference between that level's reduction and the last one's (a clock that does not run in seconds never gets here) */
+        const double t_after = now ? now(now_ctx) : 0.0;
+        const uint64_t clk_ref = h->h_tree_meta[(size_t)blind * TREE_META + 6];
+        for (int it = 0; it < blind; it++) {
+            const uint64_t *m = h->h_tree_meta + (size_t)(it + 1) * TREE_META;
+            const uint64_t nchild = m[0];
+            const bool stored = it + 1 < max_levels;
+            if (!own_cap && nchild > max_nodes) { stop = true; break; }   /* wider than the caller's budget: ends the search */
+            if (fast && m[5]) { overflow = true; break; }                 /* > LIST_CAP tied leaves: the strict expansion decides */
+            if (now && t_after >= end_time && t_after - (double)(clk_ref - m[6]) * 1.0e-8 >= end_time) { stop = true; break; }
+            h->tree[it + 1].n = stored ? nchild : 1;
+            record_level(it, nchild, m + 1, stored);
+            if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
+            if (!stored) { stop = true; break; }
+        }
+        if (completed < blind) stop = true;
+    }
+    for (int it = blind; it < max_levels && !stop && !overflow; it++) {
         if (now && now(now_ctx) >= end_time) break;                       /* controller.cpp:101-103 */
         TreeLevelBuf &A = h->tree[it];
         const uint32_t n = (uint32_t)A.n;
@@ -680,19 +921,19 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         if (fast) {
             if (stored)
                 hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr);
             else
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr);
             hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
                                (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_winners);
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord);
+                                   tpb, h->d_pkey, h->d_pord, (const uint64_t *)nullptr);
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord);
+                                   tpb, h->d_pkey, h->d_pord, (const uint64_t *)nullptr);
             hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, h->d_winners);
             if (!stored)
                 hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
@@ -703,27 +944,8 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (fast && h->h_pair[4]) { overflow = true; break; }            /* > LIST_CAP tied leaves: the strict expansion decides */
         if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
-        completed = it + 1;
-        best_leaf = h->h_pair[1];
-        leaf_stored = stored;
-        evaluated += nchild;
-        steps += (uint64_t)nchild * (uint64_t)h_problem->n_substeps;
-        if (h_level_best) {
-            h_level_best[it].n_leaves = nchild;
-            h_level_best[it].best_leaf = h->h_pair[1];
-            memcpy(&h_level_best[it].best_score, &h->h_pair[3], sizeof(double));
-            memcpy(&h_level_best[it].best_cumulative, &h->h_pair[2], sizeof(double));
-        }
-        if (n_shards > 1 && it + 1 == split_level) {
-            /* every shard has expanded this level in full; from here on this one keeps a contiguous slice of its
-             * nodes (DFS order is preserved within and across shards) */
-            if (!stored) { mpc_set_err("solve_tree_shard: split_level must be below max_levels"); return MPC_ERR_INVALID; }
-            if (nchild < n_shards) { mpc_set_err("solve_tree_shard: the split level has fewer nodes than shards"); return MPC_ERR_INVALID; }
-            const uint64_t base = nchild / n_shards, extra = nchild % n_shards;
-            B.first = (size_t)(shard * base + std::min<uint64_t>(shard, extra));
-            B.n = (size_t)(base + (shard < extra ? 1 : 0));
-            if (int s = publish_level(h, it + 1)) return s;
-        }
+        record_level(it, nchild, h->h_pair, stored);
+        if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
         if (!stored) break;                                              /* nothing to expand the next level from */
     }
     HIP_TRY(hipEventRecord(ev[1], h->stream));
@@ -742,16 +964,14 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         hipLaunchKernelGGL(path_trace_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, h->d_level_ptrs, completed - 1,
                            (uint32_t)h->tree[completed - 1].n, (uint32_t)best_leaf, h->d_results);
     } else {
-        for (int l = completed; l >= 0; l--) {
-            /* best_leaf indexes level `completed` as it was EXPANDED -- whole, from the buffer's start.  A sharded search
-             * that ends at its split level has sliced that level since (first != 0 for shard > 0): the leaf is looked up
-             * in the unsliced view.  Levels above it are reached through parent links, which are relative to the view
-             * their children were expanded from (the sliced one below a split level): ptrs() as it stands. */
-            TreeLevelBuf view = h->tree[l];
-            if (l == completed) view.first = 0;
-            hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(view), l, completed,
-                               (uint32_t)best_leaf, leaf_stored ? (uint32_t)best_leaf : 0u, h->d_list_count, h->d_results);
-        }
+        /* best_leaf indexes level `completed` as it was EXPANDED -- whole, from the buffer's start.  A sharded search
+         * that ends at its split level has sliced that level since (first != 0 for shard > 0): the leaf is looked up
+         * in the unsliced view.  Levels above it are reached through parent links, which are relative to the view
+         * their children were expanded from (the sliced one below a split level): the published pointers. */
+        TreeLevelBuf view = h->tree[completed];
+        view.first = 0;
+        hipLaunchKernelGGL(trace_all_kernel, dim3(1), dim3(1), 0, h->stream, h->d_level_ptrs, ptrs(view), completed,
+                           (uint32_t)best_leaf, leaf_stored ? (uint32_t)best_leaf : 0u, h->d_results);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], h->stream));

@@ -127,17 +127,34 @@ def test_deadline_and_node_budget(solver):
     with pytest.raises(M.MpcError) as e:
         solver.solve_tree(p, depth, now=lambda: 10.0, end_time=5.0)
     assert e.value.status == 5 and "failed to complete a single iteration" in str(e.value)
-    # the clock passes the deadline after a fixed number of polls: the deepest COMPLETED level is returned
-    calls = {"n": 0}
+    # The clock passes the deadline after a fixed number of polls: the deepest COMPLETED level is returned.  Polls: one
+    # before and one after the shallow batch (levels 1-4, expanded without host round trips), then before and after
+    # every further level; a level that completes after the deadline is discarded (controller.cpp:101-103).
+    for polls_before_deadline, want_levels in ((2, 4), (3, 4), (4, 5)):
+        calls = {"n": 0}
 
-    def clock():
-        calls["n"] += 1
-        return 0.0 if calls["n"] <= 4 else 100.0            # polls: before/after level 0, before/after level 1
-    res, levels = solver.solve_tree(p, depth, now=clock, end_time=50.0)
-    assert res.levels == 2
-    it, traj, olev, nodes = _oracle_tree(p, 2)
-    assert levels[1].best_leaf == olev[1].best_leaf
-    assert res.first_rudder == traj[1].last_rudder and res.first_throttle == traj[1].last_throttle
+        def clock():
+            calls["n"] += 1
+            return 0.0 if calls["n"] <= polls_before_deadline else 100.0
+        res, levels = solver.solve_tree(p, depth, now=clock, end_time=50.0)
+        assert res.levels == want_levels, (polls_before_deadline, res.levels)
+        it, traj, olev, nodes = _oracle_tree(p, want_levels)
+        assert levels[want_levels - 1].best_leaf == olev[want_levels - 1].best_leaf
+        assert res.first_rudder == traj[1].last_rudder and res.first_throttle == traj[1].last_throttle
+    # a real clock whose deadline falls INSIDE the shallow batch: the levels whose reduction the GPU's own clock places
+    # before the deadline count; however many that is on this box, the answer is that depth's search
+    import time
+    for budget in (20e-6, 60e-6, 150e-6, 400e-6):
+        t0 = time.perf_counter()
+        try:
+            res, levels = solver.solve_tree(p, 4, now=time.perf_counter, end_time=t0 + budget)
+        except M.MpcError as e:
+            assert e.status == 5
+            continue
+        assert 1 <= res.levels <= 4
+        it, traj, olev, nodes = _oracle_tree(p, res.levels)
+        assert levels[res.levels - 1].best_leaf == olev[res.levels - 1].best_leaf
+        assert res.first_rudder == traj[1].last_rudder and res.first_throttle == traj[1].last_throttle
     # a level wider than max_nodes ends the search the same way
     res, levels = solver.solve_tree(p, depth, max_nodes=1000)
     assert res.levels == 2                                   # level 3 has 3745 leaves
@@ -181,9 +198,9 @@ def test_sharded_search_that_ends_at_its_split_level(solver, prec, how):
         if how == "deadline":
             calls = [0]
 
-            def now():                       # polled at the top of an iteration and after its level: 2 polls per level
+            def now():                       # polled before and after the shallow batch (here: up to the split level), then per level
                 calls[0] += 1
-                return 0.0 if calls[0] <= 2 * split else 2.0
+                return 0.0 if calls[0] <= 2 else 2.0
             res, lv = solver.solve_tree(p, depth, precision=prec, now=now, end_time=1.0, split_level=split, shard=shard, n_shards=n_shards)
         else:                                # level 3 has 3745 leaves: no shard's slice of it fits 1000 nodes
             res, lv = solver.solve_tree(p, depth, precision=prec, max_nodes=1000, split_level=split, shard=shard, n_shards=n_shards)
