@@ -106,7 +106,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MPC_HIP_LIB") or LIB_PATH      # MPC_HIP_LIB: another build of the library (A/B measurements)
     # One HIP runtime per process: torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Loading
     # torch FIRST makes libmpc_hip.so bind to that copy; the other order leaves two runtimes in the process and
     # torch then sees no device.

@@ -449,9 +449,9 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
      * stay small; beyond that the winner is rolled out again by one lane, which is then noise */
     int snap_depth = 0;
     for (uint32_t p = 0; p < h->n_probs; p++) snap_depth = std::max(snap_depth, (int)h->depth[p]);
-    const size_t snap_need = (size_t)h->n_probs * count * snap_depth * SNAP_FIELDS;
+    const size_t snap_need = (size_t)h->n_probs * count * snap_slots(snap_depth) * SNAP_FIELDS;     /* every SNAP_STRIDE-th level */
     double *d_snap = nullptr;
-    if (!use_static && snap_need * sizeof(double) <= MPC_SNAPSHOT_BYTES_MAX) {
+    if (!use_static && snap_need > 0 && snap_need * sizeof(double) <= MPC_SNAPSHOT_BYTES_MAX) {
         if (int s = ensure_buffer(h, (void **)&wm.d_snap, &wm.cap_snap, sizeof(double) * snap_need)) return s;
         d_snap = wm.d_snap;
     }

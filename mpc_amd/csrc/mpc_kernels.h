@@ -88,6 +88,13 @@ __device__ inline double clampd(double v, double lo, double hi) { return v < lo 
  * that the LDS waits then have to drain.  base == nullptr = no snapshots. */
 #define SNAP_PAIRS 5
 #define SNAP_FIELDS (2 * SNAP_PAIRS)
+/* Only every SNAP_STRIDE-th level is written (the states after levels S-1, 2S-1, ...: slot (l+1)/S - 1): K2's thread
+ * for level l starts from the nearest slot below (or the start state) and integrates the <= S-1 levels in between with
+ * the code K1 ran -- the same bits -- all levels in parallel.  Every level (round 1) was 84 MB per config-2 solve,
+ * 8x the bytes the problem needs; every 4th is 21 MB for ~7 us more latency of a synchronous solve's finish, and nothing
+ * for a stream of solves, whose finish rides under the next rollout launch. */
+#define SNAP_STRIDE 4
+__host__ __device__ inline int snap_slots(int depth) { return depth / SNAP_STRIDE; }
 /* K1's side.  The stores are buffer stores with the WRITE-THROUGH cache policy (sc0 sc1): 94 MB of snapshots per
  * config-2 solve otherwise sit dirty in the XCDs' L2s until the end-of-kernel write-back, which then delays the
  * next dispatch (measured: plain 42.1 us K1 / 58.7 us per solve, nontemporal 40.0 / 56.3, write-through 39.6 / 55.6;
@@ -112,11 +119,11 @@ struct SnapW {
 __device__ inline SnapW snap_writer(double *problem_base, uint64_t count, int snap_depth, uint64_t i)
 {
     SnapW w;
-    const uint64_t bytes = (uint64_t)snap_depth * SNAP_PAIRS * count * 16;      /* <= MPC_SNAPSHOT_BYTES_MAX (host) */
+    const uint64_t bytes = (uint64_t)snap_slots(snap_depth) * SNAP_PAIRS * count * 16;      /* <= MPC_SNAPSHOT_BYTES_MAX (host) */
     w.rsrc = __builtin_amdgcn_make_buffer_rsrc(problem_base, 0, (int)(uint32_t)bytes, 0x00020000);
     w.pair_bytes = (uint32_t)(count * 16);
     w.lane_off = (uint32_t)(i * 16);
-    w.on = problem_base != nullptr;
+    w.on = problem_base != nullptr && bytes != 0;
     return w;
 }
 
@@ -140,6 +147,17 @@ struct Snap {
 /* Both evaluators: UNIFORM = every substep of a level has the same length (BASELINE configs 2-5: 20 x 0.05 s), so
  * the schedule row lives in registers instead of being re-read from LDS 400 times per candidate. */
 
+/* one level and its score, the strict model: the ONE spelling K1 (eval_strict) and K2 (re-integration between
+ * snapshot slots) share, so that both produce the same bits */
+template <bool UNIFORM>
+__device__ inline double strict_level_and_score(const DevProblem &P, const Model &M, const Weights &w, const double *cpL,
+                                                const double *subL, const double *row0, int l, double r, double t, Veh &s)
+{
+    if (UNIFORM) strict_level<0>(s, r, t, row0, P.nsub, P.cx, P.cy, M);
+    else strict_level<SUB_STRIDE>(s, r, t, subL, P.nsub, P.cx, P.cy, M);
+    return strict_score(cpL + l * CP_STRIDE, s, w);
+}
+
 /* strict evaluation of one candidate; traj (optional) receives depth+1 level states */
 template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
 __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const double *subL,
@@ -155,16 +173,15 @@ __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const
     for (int l = 0; l < P.depth; l++) {
         double r, t;
         fetch_control<SEEDED, STAGED>(c, ordinal, index, l, r, t);
-        if (UNIFORM) strict_level<0>(s, r, t, row0, P.nsub, P.cx, P.cy, M);
-        else strict_level<SUB_STRIDE>(s, r, t, subL, P.nsub, P.cx, P.cy, M);
-        last = strict_score(cpL + l * CP_STRIDE, s, w);
+        last = strict_level_and_score<UNIFORM>(P, M, w, cpL, subL, row0, l, r, t, s);
         cum += last;
         if (traj)
             traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog,
                                           clampd(r, -1, 1), clampd(t, 0, 1), cum};
-        if (snap.on) {
-            snap.put2(l, 0, s.x, s.y); snap.put2(l, 1, s.h, s.v); snap.put2(l, 2, s.rpm, s.cmg);
-            snap.put2(l, 3, s.sog, cum); snap.put2(l, 4, last, 0.0);
+        if (snap.on && ((l + 1) % SNAP_STRIDE) == 0) {
+            const int q = (l + 1) / SNAP_STRIDE - 1;
+            snap.put2(q, 0, s.x, s.y); snap.put2(q, 1, s.h, s.v); snap.put2(q, 2, s.rpm, s.cmg);
+            snap.put2(q, 3, s.sog, cum); snap.put2(q, 4, last, 0.0);
         }
     }
 }
@@ -181,6 +198,24 @@ __device__ inline mpc_level_state fast_to_level_state(const double *cp, const do
     /* cp[0] - cp[6] = cx * T_l: the current's share of the displacement, common to all candidates */
     return mpc_level_state{x + (cp[0] - cp[6]), y + (cp[1] - cp[7]), h, v, rpm, PI_2 - atan2(gdy, gdx), sog,
                            clampd(r, -1, 1), clampd(t, 0, 1), cum};
+}
+
+/* one level and its score, the fast model: shared by K1 and K2 like strict_level_and_score.  The checkpoint's words are
+ * read before the substep loop (a lone wave has nothing to hide their LDS latency behind). */
+template <bool UNIFORM>
+__device__ inline double fast_level_and_score(const DevProblem &P, const Model &M, const Weights &w, const double *cpL,
+                                              const double *subL, const double *row0, const double *q_last, int l,
+                                              double r, double t, FastVeh &s)
+{
+    const double *cpv = cpL + l * CP_STRIDE;
+    double cp[CP_STRIDE];
+    cp[3] = cpv[3]; cp[4] = cpv[4]; cp[5] = cpv[5]; cp[6] = cpv[6]; cp[7] = cpv[7];
+    /* not the LEAN spellings (mpc_model.h): a candidate's cost must not depend on how its set was supplied or
+     * sized, and config 2 -- one wave per SIMD -- is 0.6 us faster without them */
+    if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub, M);
+    else if (P.head_uniform) fast_level_head_uniform(s, r, t, subL, P.nsub, M);
+    else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub, M);
+    return fast_score(cp, s, w, q_last);
 }
 
 template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
@@ -204,22 +239,15 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
     for (int l = 0; l < P.depth; l++) {
         const double r = r_next, t = t_next;
         fetch_control<SEEDED, STAGED>(c, ordinal, index, min(l + 1, P.depth - 1), r_next, t_next);
-        const double *cpv = cpL + l * CP_STRIDE;
-        double cp[CP_STRIDE];
-        cp[3] = cpv[3]; cp[4] = cpv[4]; cp[5] = cpv[5]; cp[6] = cpv[6]; cp[7] = cpv[7];
-        /* not the LEAN spellings (mpc_model.h): a candidate's cost must not depend on how its set was supplied or
-         * sized, and config 2 -- one wave per SIMD -- is 0.6 us faster without them */
-        if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub, M);
-        else if (P.head_uniform) fast_level_head_uniform(s, r, t, subL, P.nsub, M);
-        else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub, M);
-        last = fast_score(cp, s, w, q_last);
+        last = fast_level_and_score<UNIFORM>(P, M, w, cpL, subL, row0, q_last, l, r, t, s);
         cum += last;
         if (traj)
             traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta,
                                               r, t, cum);
-        if (snap.on) {
-            snap.put2(l, 0, s.x, s.y); snap.put2(l, 1, s.sh, s.ch); snap.put2(l, 2, s.v, s.rpm);
-            snap.put2(l, 3, cum, last);
+        if (snap.on && ((l + 1) % SNAP_STRIDE) == 0) {
+            const int q = (l + 1) / SNAP_STRIDE - 1;
+            snap.put2(q, 0, s.x, s.y); snap.put2(q, 1, s.sh, s.ch); snap.put2(q, 2, s.v, s.rpm);
+            snap.put2(q, 3, cum, last);
         }
     }
 }
@@ -348,28 +376,62 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
         }
         return;
     }
-    if (snap_base && (keep_fast || !fast)) {
-        /* K1 left every candidate's per-level state in HBM: one thread per level converts the winner's */
-        const Snap snap{snap_base + (uint64_t)p * snap_depth * SNAP_FIELDS * count, count, win - first};
+    if (snap_base && snap_slots(snap_depth) > 0 && (keep_fast || !fast)) {
+        /* K1 left every candidate's state after every SNAP_STRIDE-th level in HBM.  One thread per level: start from the
+         * nearest slot below (or the start state) and integrate the <= SNAP_STRIDE - 1 levels in between with K1's own
+         * code (strict/fast_level_and_score, the flavour K1 ran): the same bits as K1 had in its registers. */
+        const Snap snap{snap_base + (uint64_t)p * snap_slots(snap_depth) * SNAP_FIELDS * count, count, win - first};
         const int l = threadIdx.x;
+        double *s_tail = (double *)(small + 12);       /* [0] = last, [1] = cum of the last level (words 12, 13 of the small state) */
         if (l < P.depth) {
-            double r, t;
-            fetch_control<SEEDED>(c, win, win - first, l, r, t);
+            const Weights w{P.wd, P.wh, P.ws};
+            const Model M = P.model;
+            const int g = (l + 1) / SNAP_STRIDE;           /* slots at or below level l */
+            const int from = g * SNAP_STRIDE;              /* first level to integrate (== l + 1: none) */
+            double r = 0, t = 0, cum = 0, last = 0;
             if (fast) {
-                /* delta = v * (last substep's dt), as fast_level leaves it */
                 const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
-                const double v = snap.get(l, 4);
-                R.traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last,
-                                                    snap.get(l, 0), snap.get(l, 1), snap.get(l, 2), snap.get(l, 3),
-                                                    v, snap.get(l, 5), v * q_last[0], r, t, snap.get(l, 6));
+                const double row0[6] = {subL[0], subL[1], subL[2], subL[3], subL[4], subL[5]};
+                FastVeh s;
+                if (g == 0) {
+                    s.x = P.sx; s.y = P.sy; s.v = P.sv; s.rpm = P.srpm; s.delta = 0;
+                    sincos(P.sh, &s.sh, &s.ch);
+                } else {
+                    const int q = g - 1;
+                    s.x = snap.get(q, 0); s.y = snap.get(q, 1); s.sh = snap.get(q, 2); s.ch = snap.get(q, 3);
+                    s.v = snap.get(q, 4); s.rpm = snap.get(q, 5); cum = snap.get(q, 6); last = snap.get(q, 7);
+                    s.delta = s.v * q_last[0];             /* v * (last substep's dt), as fast_level leaves it */
+                }
+                for (int j = from; j <= l; j++) {
+                    fetch_control<SEEDED>(c, win, win - first, j, r, t);
+                    last = uniform ? fast_level_and_score<true>(P, M, w, cpL, subL, row0, q_last, j, r, t, s)
+                                   : fast_level_and_score<false>(P, M, w, cpL, subL, row0, q_last, j, r, t, s);
+                    cum += last;
+                }
+                if (from > l) fetch_control<SEEDED>(c, win, win - first, l, r, t);
+                R.traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta, r, t, cum);
+            } else {
+                const double row0[1] = {subL[0]};
+                Veh s{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
+                if (g > 0) {
+                    const int q = g - 1;
+                    s = Veh{snap.get(q, 0), snap.get(q, 1), snap.get(q, 2), snap.get(q, 3), snap.get(q, 4), snap.get(q, 5), snap.get(q, 6)};
+                    cum = snap.get(q, 7); last = snap.get(q, 8);
+                }
+                for (int j = from; j <= l; j++) {
+                    fetch_control<SEEDED>(c, win, win - first, j, r, t);
+                    last = uniform ? strict_level_and_score<true>(P, M, w, cpL, subL, row0, j, r, t, s)
+                                   : strict_level_and_score<false>(P, M, w, cpL, subL, row0, j, r, t, s);
+                    cum += last;
+                }
+                if (from > l) fetch_control<SEEDED>(c, win, win - first, l, r, t);
+                R.traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog, clampd(r, -1, 1), clampd(t, 0, 1), cum};
             }
-            else
-                R.traj[l + 1] = mpc_level_state{snap.get(l, 0), snap.get(l, 1), snap.get(l, 2), snap.get(l, 3),
-                                                snap.get(l, 4), snap.get(l, 5), snap.get(l, 6),
-                                                clampd(r, -1, 1), clampd(t, 0, 1), snap.get(l, 7)};
+            if (l == P.depth - 1) { s_tail[0] = last; s_tail[1] = cum; }
         }
+        __syncthreads();
         if (threadIdx.x == 0) {
-            const double last = snap.get(P.depth - 1, fast ? 7 : 8), cum = snap.get(P.depth - 1, fast ? 6 : 7);
+            const double last = s_tail[0], cum = s_tail[1];
             const uint64_t kb = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
             R.traj[0] = mpc_level_state{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
             R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
@@ -459,7 +521,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
     if (i < count) {
         const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
                               SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x};
-        const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_depth * SNAP_FIELDS * count : nullptr,
+        const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_slots(snap_depth) * SNAP_FIELDS * count : nullptr,
                                        count, snap_depth, i);
         double last, cum;
         if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
