@@ -72,14 +72,14 @@ def measured_valu(k1_seconds):
     rate 256 CU x 4 SIMD x 16 lanes x 2.4 GHz).  The instruction count comes from the committed PMC pass of this
     command (counters cannot be read inside the timed process), the time is this run's."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
         insts = float(prof["sq_insts_valu"])
     except Exception:
         return None
     out = {"sq_insts_valu_per_launch": insts, "lane_issue_frac": insts * 64 / (k1_seconds * 256 * 4 * 16 * 2.4e9),
-           "source": "profiles/r01_pmc_summary.json (SQ_INSTS_VALU) / this run's kernel time"}
+           "source": "profiles/r02_pmc_summary.json (SQ_INSTS_VALU) / this run's kernel time"}
     try:        # hardware-counted FP64 operations (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 lanes, FMA = 2 FLOP)
-        for ln in open(os.path.join(ROOT, "profiles", "r01_fp64_flop_counters.txt")):
+        for ln in open(os.path.join(ROOT, "profiles", "r02_fp64_flop_counters.txt")):
             if ln.startswith("config2 |"):
                 flop = float(ln.split("|")[5])
                 out["counted_fp64_flop_per_launch"] = flop
@@ -93,7 +93,7 @@ def measured_valu(k1_seconds):
 def measured_traffic():
     """HBM bytes per rollout-kernel launch from the committed PMC profile of this same command (rocprofv3 --pmc
     cannot run inside the timed process); None if no profile has been committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
         return json.load(open(path))["hbm_bytes_per_launch"]
     except Exception:
@@ -315,7 +315,7 @@ def main():
                 "kernel": "rollout_kernel", "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flop / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": measured_traffic() if args.workload == "config2" and prec == M.PREC_FAST else None,
-                "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+                "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                 "measured_valu": measured_valu(k1_ms * 1e-3) if args.workload == "config2" and prec == M.PREC_FAST else None,
                 "algorithmic_flop_per_launch": flop, "kernel_steps_per_sec": steps_per_solve / (k1_ms * 1e-3),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,

@@ -65,11 +65,12 @@ for (kern, ctr), (s, n) in sorted(acc.items()):
         k1[ctr] = s / n
 open(os.path.join(out, tag + "_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 summary = {
-    "kernel": "rollout_kernel<fast, explicit, uniform schedule>", "workload": "config 2 (65536 x 20 x 20)",
+    "kernel": "rollout_kernel<fast, explicit, uniform schedule, fused finish of the previous solve>", "workload": "config 2 (65536 x 20 x 20)",
     "fetch_size_kib": k1["FETCH_SIZE"], "write_size_kib": k1["WRITE_SIZE"],
     "hbm_bytes_per_launch": int(round((2 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024)),
-    "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per the gfx950 correction; 83.9 MB of the "
-            "writes are the per-level state snapshots (65536 x 20 levels x 4 pairs x 16 B) that replace the winner's second rollout",
+    "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per the gfx950 correction; 21 MB of the "
+            "writes are the state snapshots of every 4th level (65536 x 5 slots x 4 pairs x 16 B) that replace the winner's "
+            "second rollout (round 1 wrote every level: 83.9 MB); the launch also carries the previous solve's finish workgroup",
     "sq_insts_valu": k1["SQ_INSTS_VALU"], "sq_waves": k1["SQ_WAVES"], "sq_wave_cycles_quad": k1["SQ_WAVE_CYCLES"],
     "sq_active_inst_valu_quad": k1["SQ_ACTIVE_INST_VALU"], "sq_wait_any_quad": k1.get("SQ_WAIT_ANY"),
     "grbm_gui_active": k1["GRBM_GUI_ACTIVE"],
