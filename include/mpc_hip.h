@@ -244,6 +244,19 @@ typedef struct { double x, y, heading, speed, time, rudder, throttle; } mpc_hist
 int         mpc_hip_estimate_currents(mpc_hip_handle *h, const mpc_history_sample *h_samples, const uint32_t *h_counts,
                                       uint32_t stride, const double *h_actual, uint32_t n, int apply,
                                       double *h_currents_out);
+/* The same estimate from DEVICE-RESIDENT histories: CurrentEstimator's own state for a fleet kept in HBM, so that a
+ * tick uploads one sample per vessel (56 B) instead of every vessel's whole history (138 MB for 4096 x 600).
+ *   mpc_hip_history_reset(h, n)        resetEstimate (CurrentEstimator.h:43-47) for n vessels: empty rings, 20 skips left
+ *   mpc_hip_history_update(h, s, n)    updateEstimate (CurrentEstimator.cpp:5-13) for every vessel, one kernel:
+ *                                      h_samples[p] = the State at this update + the controls in effect; the first 20
+ *                                      updates after a reset are dropped, the ring keeps the newest 600
+ *   mpc_hip_estimate_currents_resident getCurrent (:15-41) from the rings; arguments as mpc_hip_estimate_currents
+ * The rings are field-major SoA [7][600][n]: the 64 lanes of a wave read 512 contiguous bytes per field (the uploaded
+ * form is array-of-structs per vessel, lanes 33.6 KB apart).  Same arithmetic, same bits as the uploaded form. */
+int         mpc_hip_history_reset(mpc_hip_handle *h, uint32_t n_vessels);
+int         mpc_hip_history_update(mpc_hip_handle *h, const mpc_history_sample *h_samples, uint32_t n);
+int         mpc_hip_estimate_currents_resident(mpc_hip_handle *h, const double *h_actual, uint32_t n, int apply,
+                                               double *h_currents_out);
 /* copy the results of the last run (n_problems of them) to the host; synchronises the stream */
 int         mpc_hip_fetch_results(mpc_hip_handle *h, mpc_result *h_results, uint32_t n_problems);
 /* device address of the per-problem packed winners of the last run: for problem p two uint64,

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_abi_version", "mpc_hip_status_string", "mpc_hip_last_error", "mpc_hip_default_problem",
     "mpc_hip_substep_schedule", "mpc_hip_default_model", "mpc_hip_set_model", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
-    "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_run_seeded", "mpc_hip_run_seeded_static", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
+    "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_history_reset", "mpc_hip_history_update", "mpc_hip_estimate_currents_resident", "mpc_hip_run_seeded", "mpc_hip_run_seeded_static", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
     "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_rescore_tied_shards", "mpc_hip_set_pipeline", "mpc_hip_flush", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
 )
 
@@ -145,6 +145,9 @@ def load_library(path=None):
     L.mpc_hip_fetch_checkpoints.argtypes = [vp, C.c_uint32, C.POINTER(Checkpoint)]
     L.mpc_hip_estimate_currents.argtypes = [vp, C.POINTER(HistorySample), C.POINTER(C.c_uint32), C.c_uint32, dp, C.c_uint32,
                                             i32, dp]
+    L.mpc_hip_history_reset.argtypes = [vp, C.c_uint32]
+    L.mpc_hip_history_update.argtypes = [vp, C.POINTER(HistorySample), C.c_uint32]
+    L.mpc_hip_estimate_currents_resident.argtypes = [vp, dp, C.c_uint32, i32, dp]
     L.mpc_hip_set_winner_sink.argtypes = [vp, vp]
     L.mpc_hip_set_pipeline.argtypes = [vp, i32]
     L.mpc_hip_flush.argtypes = [vp]
@@ -320,6 +323,25 @@ class Solver:
         act = (C.c_double * (3 * n))(*[float(v) for a3 in actual for v in a3])
         out = (C.c_double * (2 * n))()
         _check(self._L.mpc_hip_estimate_currents(self._h, flat, counts, stride, act, n, int(bool(apply)), out))
+        return [(out[2 * p], out[2 * p + 1]) for p in range(n)]
+
+    def history_reset(self, n_vessels):
+        """device-resident CurrentEstimator state for a fleet: empty rings, 20 skips left (resetEstimate)"""
+        _check(self._L.mpc_hip_history_reset(self._h, int(n_vessels)))
+
+    def history_update(self, samples):
+        """updateEstimate for every vessel: samples[p] = HistorySample or 7-tuple (x, y, heading, speed, time, rudder, throttle)"""
+        n = len(samples)
+        arr = samples if isinstance(samples, C.Array) else (HistorySample * n)(
+            *[e if isinstance(e, HistorySample) else HistorySample(*[float(v) for v in e]) for e in samples])
+        _check(self._L.mpc_hip_history_update(self._h, arr, n))
+
+    def estimate_currents_resident(self, actual, apply=False):
+        """getCurrent for every vessel from the device-resident rings; actual: per vessel (x, y, time) -> [(cx, cy)]"""
+        n = len(actual)
+        act = (C.c_double * (3 * n))(*[float(v) for a3 in actual for v in a3])
+        out = (C.c_double * (2 * n))()
+        _check(self._L.mpc_hip_estimate_currents_resident(self._h, act, n, int(bool(apply)), out))
         return [(out[2 * p], out[2 * p + 1]) for p in range(n)]
 
     def run_seeded(self, first, count, precision=PREC_FAST, selection=SELECT_LAST_STEP, d_cost_last=None,

@@ -152,6 +152,7 @@ extern "C" void mpc_hip_destroy(mpc_hip_handle *h)
     (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord);
     for (WorkMem &w : h->wm) { (void)hipFree(w.d_keys); (void)hipFree(w.d_snap); (void)hipFree(w.d_pkey); (void)hipFree(w.d_pord); (void)hipFree(w.d_pcnt); }
     (void)hipFree(h->d_controls); (void)hipFree(h->d_models); (void)hipFree(h->d_tied_rows); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
+    (void)hipFree(h->d_hist_ring); (void)hipFree(h->d_hist_state); (void)hipFree(h->d_hist_io); (void)hipHostFree(h->h_hist_io);
     mpc_tree_free(h);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);

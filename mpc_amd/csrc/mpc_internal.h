@@ -139,6 +139,9 @@ struct mpc_hip_handle {
     mpc::Model *d_models = nullptr; size_t cap_models = 0;       /* device copy (fleet current estimation) */
     void *d_plans = nullptr; size_t cap_plans = 0;              /* mpc_plan[P] + start times (mpc_plan.hip) */
     void *d_hist = nullptr; size_t cap_hist = 0;                /* histories, counts, query states, estimates (mpc_current.hip) */
+    void *d_hist_ring = nullptr, *d_hist_state = nullptr;       /* device-resident histories: ring[7][600][n], per-vessel state */
+    void *d_hist_io = nullptr, *h_hist_io = nullptr;            /* one sample (or query + estimate) per vessel, device / pinned */
+    uint32_t hist_n = 0;
 
     /* tree search */
     std::vector<TreeLevelBuf> tree;

@@ -122,3 +122,73 @@ def test_fleet_with_applied_currents_equals_host_upload(solver):
                 for r in solver.eval_seeded_batch(ref_probs, seeds, n, prec)]
         assert got == want                            # the same records, bit for bit
         assert all(g[0] == 0 for g in got)
+
+
+def test_device_resident_histories_equal_the_uploaded_ones():
+    """mpc_hip_history_reset / _update / mpc_hip_estimate_currents_resident: CurrentEstimator's own state for a fleet kept
+    in HBM.  A fleet of 37 vessels is ticked 700 times (the reference drops the first 20 updates after a reset and keeps
+    the newest 600: CurrentEstimator.cpp:5-13); at several ticks the resident estimate must equal, bit for bit, the
+    uploaded-history entry point given the history a CurrentEstimator would hold then, which in turn is checked against
+    the oracle."""
+    solver = M.Solver(0)
+    try:
+        rng = np.random.RandomState(23)
+        n = 37
+        vessels, kept = [], [[] for _ in range(n)]
+        for p in range(n):
+            cur = (rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4))
+            start = (rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(0, 6.28), rng.uniform(0.5, 2.75), 100.0 + p)
+            vessels.append([O.vehicle(*start), cur, 0.0, 0.5])
+        solver.history_reset(n)
+        skips = 20
+        for tick in range(700):
+            samples = []
+            for p, ves in enumerate(vessels):
+                v, cur, r, t = ves
+                if (tick + p) % 9 == 0:
+                    ves[2], ves[3] = r, t = float(rng.randint(-16, 17)) * 0.0625, float(rng.randint(0, 9)) * 0.125
+                samples.append((v.s.x, v.s.y, v.s.heading, v.s.speed, v.s.time, r, t))
+                if tick >= skips:
+                    kept[p].append(O.HistoryEntry(v.s, r, t))
+                    if len(kept[p]) > M.binding.CURRENT_MAX_SAMPLES:
+                        kept[p].pop(0)
+                ves[0] = O.simulate(v, r, t, 0.1 + rng.uniform(-0.01, 0.01), cur[0], cur[1])
+            solver.history_update(samples)
+            if tick in (5, 19, 25, 29, 30, 31, 200, 619, 620, 621, 699):
+                actual = [(ves[0].s.x, ves[0].s.y, ves[0].s.time) for ves in vessels]
+                resident = solver.estimate_currents_resident(actual)
+                uploaded = solver.estimate_currents([_as_samples(h) for h in kept], actual)
+                assert resident == uploaded, tick                                    # same arithmetic, same bits
+                for p in (0, 17, 36):
+                    want = O.current_estimate(kept[p], True, vessels[p][0].s)
+                    assert abs(resident[p][0] - want[0]) <= TOL * max(1.0, abs(want[0])), (tick, p)
+                    assert abs(resident[p][1] - want[1]) <= TOL * max(1.0, abs(want[1])), (tick, p)
+                if tick < 29:
+                    assert all(c == (0.0, 0.0) for c in resident)                    # 20 skipped + fewer than 10 kept
+        assert len(kept[0]) == 600
+        # apply: the estimates become the resident problems' currents, as the uploaded form does
+        probs, seeds = W.fleet_problems(n, depth=6)
+        solver.upload(probs, seeds)
+        actual = [(ves[0].s.x, ves[0].s.y, ves[0].s.time) for ves in vessels]
+        cur = solver.estimate_currents_resident(actual, apply=True)
+        a = solver.eval_seeded_batch([_with_current(q, c) for q, c in zip(probs, cur)], seeds, 512, M.PREC_FAST)
+        solver.upload(probs, seeds)
+        solver.estimate_currents_resident(actual, apply=True)
+        solver.run_seeded(0, 512, M.PREC_FAST)
+        b = solver.fetch()
+        assert [(r.best_ordinal, r.best_last) for r in a] == [(r.best_ordinal, r.best_last) for r in b]
+        # a reset empties the rings
+        solver.history_reset(n)
+        assert all(c == (0.0, 0.0) for c in solver.estimate_currents_resident(actual))
+        with pytest.raises(M.MpcError):
+            solver.history_update(samples[:5])                                       # not the fleet the rings were made for
+    finally:
+        solver.close()
+
+
+def _with_current(p, c):
+    import copy
+    q = copy.copy(p)
+    q = type(p).from_buffer_copy(bytes(p))
+    q.current_x, q.current_y = c
+    return q
