@@ -780,6 +780,7 @@ extern "C" int mpc_hip_rollout(mpc_hip_handle *h, const mpc_problem *h_problem, 
     HIP_TRY(hipStreamSynchronize(h->stream));      /* ctl is a stack buffer */
     hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
     h->timed[h->runs % TIMING_RING] = 1;
+    h->total_from_k1[h->runs % TIMING_RING] = 0;
     HIP_TRY(hipEventRecord(ev[0], h->stream));
     hipLaunchKernelGGL(rollout_one_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, h->d_controls, precision, h->d_results);
     HIP_TRY(hipGetLastError());

@@ -747,6 +747,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
 
     hipEvent_t *ev = &h->ev[4 * (h->runs % TIMING_RING)];
     h->timed[h->runs % TIMING_RING] = 1;
+    h->total_from_k1[h->runs % TIMING_RING] = 0;
     HIP_TRY(hipEventRecord(ev[0], h->stream));
     if (int s = ensure_level(h, h->tree[0], 1)) return s;
     h->tree[0].n = 1;
