@@ -473,7 +473,10 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     const dim3 grid(nblk + (fuse ? 1u : 0u), h->n_probs), blk(block);
     /* explicit sets: all levels' controls of a workgroup are staged in LDS as FP32 (<= 64 KiB by the block choice);
      * a fused finish keeps its near-tie list (+ 16 words) in the same place */
-    size_t ctl_bytes = seeded ? 0 : sizeof(float) * 2 * (size_t)snap_depth * block;
+    /* small seeded sets (fast, one-wave workgroups, depth <= 32): every level's controls are generated into LDS by the
+     * prologue (PREGEN, mpc_kernels.h): 2 * depth * 64 doubles */
+    const bool pregen = seeded && fast && block == 64 && snap_depth <= 32;
+    size_t ctl_bytes = seeded ? (pregen ? sizeof(double) * 2 * (size_t)snap_depth * block : 0) : sizeof(float) * 2 * (size_t)snap_depth * block;
     if (fuse) ctl_bytes = std::max(ctl_bytes, sizeof(uint64_t) * (LIST_CAP + FINISH_LDS_WORDS));
     const size_t lds = K1_LDS_BASE + ctl_bytes;
     if (lds > K1_LDS_LIMIT) { mpc_set_err("rollout kernel: staged controls do not fit the workgroup's LDS"); return MPC_ERR_TOO_LARGE; }
@@ -491,11 +494,18 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     hipExtLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI, FUSE>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
                        first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth,     \
                        d_pkey, d_pord, d_pcnt, prev)
-    if (fuse) { if (seeded) LAUNCH_K1U(MPC_PREC_FAST, true, true, true); else LAUNCH_K1U(MPC_PREC_FAST, false, true, true); }
+#define LAUNCH_K1P(UNI, FUSE)                                                                                 \
+    hipExtLaunchKernelGGL((rollout_kernel<MPC_PREC_FAST, true, UNI, FUSE, true>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
+                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth,     \
+                       d_pkey, d_pord, d_pcnt, prev)
+    if (fuse && pregen) LAUNCH_K1P(true, true);
+    else if (fuse) { if (seeded) LAUNCH_K1U(MPC_PREC_FAST, true, true, true); else LAUNCH_K1U(MPC_PREC_FAST, false, true, true); }
+    else if (pregen) { if (uniform) LAUNCH_K1P(true, false); else LAUNCH_K1P(false, false); }
     else if (precision == MPC_PREC_F64) { if (seeded) LAUNCH_K1(MPC_PREC_F64, true); else LAUNCH_K1(MPC_PREC_F64, false); }
     else { if (seeded) LAUNCH_K1(MPC_PREC_FAST, true); else LAUNCH_K1(MPC_PREC_FAST, false); }
 #undef LAUNCH_K1
 #undef LAUNCH_K1U
+#undef LAUNCH_K1P
     HIP_TRY(hipGetLastError());
     /* this run's finish: pending (pipeline) or launched right away */
     h->pend = FinishArgs{h->d_probs, d_rud, d_thr, first, count, selection, fast, (int)uniform, rel, nblk, cpb,

@@ -26,6 +26,7 @@ struct ControlSource {
     double last_r, last_t;
     const float *staged;         /* explicit controls of THIS lane staged in LDS by ctl_chunk_store(), or nullptr */
     uint32_t staged_stride;      /* = blockDim.x */
+    const double *pregen;        /* seeded controls of THIS lane generated into LDS by the prologue (PREGEN), or nullptr */
 };
 
 /* K1 reads every level's controls of its candidates ONCE into LDS ([level][rudder|throttle][lane], FP32), CTL_CHUNK
@@ -63,11 +64,18 @@ __device__ inline void ctl_chunk_store(float *ctl, int depth, int base, const fl
 /* STAGED is a compile-time choice on purpose: a run-time choice between the LDS copy and the global arrays makes
  * hipcc select between two pointers and emit flat_ loads, whose vmcnt(0)+lgkmcnt(0) wait also drains every
  * outstanding snapshot store at the top of every level. */
-template <bool SEEDED, bool STAGED = false>
+/* PREGEN (small seeded sets: one-wave workgroups): the prologue has generated every level's controls into LDS as
+ * doubles ([level][rudder|throttle][lane]), all levels' SplitMix64 chains interleaved, so that the level loop reads two
+ * LDS words instead of running a ~40-instruction dependent integer chain alone in its basic block -- on a lone wave
+ * that chain cost 7 us per 65,536-candidate solve (round 1).  Launches that fill the SIMDs generate in place. */
+template <bool SEEDED, bool STAGED = false, bool PREGEN = false>
 __device__ inline void fetch_control(const ControlSource &c, uint64_t ordinal, uint64_t index, int level,
                                      double &r, double &t)
 {
-    if (SEEDED) {
+    if (SEEDED && PREGEN) {
+        r = c.pregen[(2 * level) * c.staged_stride];
+        t = c.pregen[(2 * level + 1) * c.staged_stride];
+    } else if (SEEDED) {
         mpc_candidate_control(c.seed, ordinal, (uint32_t)level, c.last_r, c.last_t, &r, &t);
     } else if (STAGED) {
         r = (double)c.staged[(2 * level) * c.staged_stride];
@@ -159,7 +167,7 @@ __device__ inline double strict_level_and_score(const DevProblem &P, const Model
 }
 
 /* strict evaluation of one candidate; traj (optional) receives depth+1 level states */
-template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
+template <bool SEEDED, bool UNIFORM = false, bool STAGED = false, bool PREGEN = false>
 __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const double *subL,
                                    const ControlSource &c, uint64_t ordinal, uint64_t index,
                                    double &last, double &cum, mpc_level_state *traj, const SnapW snap)
@@ -172,7 +180,7 @@ __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const
     if (traj) traj[0] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
     for (int l = 0; l < P.depth; l++) {
         double r, t;
-        fetch_control<SEEDED, STAGED>(c, ordinal, index, l, r, t);
+        fetch_control<SEEDED, STAGED, PREGEN>(c, ordinal, index, l, r, t);
         last = strict_level_and_score<UNIFORM>(P, M, w, cpL, subL, row0, l, r, t, s);
         cum += last;
         if (traj)
@@ -218,7 +226,7 @@ __device__ inline double fast_level_and_score(const DevProblem &P, const Model &
     return fast_score(cp, s, w, q_last);
 }
 
-template <bool SEEDED, bool UNIFORM = false, bool STAGED = false>
+template <bool SEEDED, bool UNIFORM = false, bool STAGED = false, bool PREGEN = false>
 __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const double *subL,
                                  const ControlSource &c, uint64_t ordinal, uint64_t index,
                                  double &last, double &cum, mpc_level_state *traj, const SnapW snap)
@@ -235,10 +243,10 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
     /* A lone wave per SIMD has nothing to hide a latency behind, so what a level reads from LDS is requested one
      * substep loop ahead: level l+1's controls and level l's checkpoint are in flight while level l integrates. */
     double r_next = 0, t_next = 0;
-    if (P.depth > 0) fetch_control<SEEDED, STAGED>(c, ordinal, index, 0, r_next, t_next);
+    if (P.depth > 0) fetch_control<SEEDED, STAGED, PREGEN>(c, ordinal, index, 0, r_next, t_next);
     for (int l = 0; l < P.depth; l++) {
         const double r = r_next, t = t_next;
-        fetch_control<SEEDED, STAGED>(c, ordinal, index, min(l + 1, P.depth - 1), r_next, t_next);
+        fetch_control<SEEDED, STAGED, PREGEN>(c, ordinal, index, min(l + 1, P.depth - 1), r_next, t_next);
         last = fast_level_and_score<UNIFORM>(P, M, w, cpL, subL, row0, q_last, l, r, t, s);
         cum += last;
         if (traj)
@@ -280,7 +288,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
     const DevProblem &P = probs[p];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (threadIdx.x == 0) s_n = 0;
-    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
+    const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0, nullptr};
     DevResult &R = results[p];
     const uint64_t *pk = pkey + (uint64_t)p * nblk, *po = pord + (uint64_t)p * nblk;
     const uint32_t *pc = pcnt + (uint64_t)p * nblk;
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs A)
  * finishes solve n -- which serialises the same chain behind the rollout: slower than two kernels.)  Its LDS comes out
  * of the dynamic allocation: the problem staging area it shares by layout, the near-tie list sits where a rollout
  * workgroup keeps its controls (the host sizes the allocation for both). */
-template <int PREC, bool SEEDED, bool UNIFORM, bool FUSE = false>
+template <int PREC, bool SEEDED, bool UNIFORM, bool FUSE = false, bool PREGEN = false>
 __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restrict__ probs,
                                                       const float *__restrict__ rud, const float *__restrict__ thr,
                                                       uint64_t first, uint64_t count, int selection, double refine_rel,
@@ -516,16 +524,32 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
             ctl_chunk_store(ctlL, snap_depth, base, ca, cb);
         }
     }
+    double *genL = (double *)ctlL;                                             /* [depth][2][blockDim] doubles (PREGEN) */
+    if (SEEDED && PREGEN) {
+        /* every level's controls of this lane, the levels' hash chains independent of one another (unrolled x4: a lone
+         * wave issues one chain's next instruction while another's result is in flight); each lane reads back only
+         * what it wrote: no barrier */
+        const uint64_t ord = first + ic;
+        const int depth = P.depth;
+#pragma unroll 4
+        for (int l = 0; l < depth; l++) {
+            double r, t;
+            mpc_candidate_control(P.seed, ord, (uint32_t)l, P.last_r, P.last_t, &r, &t);
+            genL[(2 * l) * blockDim.x + threadIdx.x] = r;
+            genL[(2 * l + 1) * blockDim.x + threadIdx.x] = t;
+        }
+    }
     uint64_t k = ~0ull, o = ~0ull;
     double mykey = __longlong_as_double((long long)KEY_INF);
     if (i < count) {
         const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
-                              SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x};
+                              SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x,
+                              (SEEDED && PREGEN) ? genL + threadIdx.x : nullptr};
         const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_slots(snap_depth) * SNAP_FIELDS * count : nullptr,
                                        count, snap_depth, i);
         double last, cum;
-        if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
-        else eval_fast<SEEDED, UNIFORM, !SEEDED>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
+        if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED, PREGEN>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
+        else eval_fast<SEEDED, UNIFORM, !SEEDED, PREGEN>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
         const uint64_t at = (uint64_t)blockIdx.y * count + i;
         if (cost_last) cost_last[at] = last;
         if (cost_cum) cost_cum[at] = cum;
@@ -601,7 +625,7 @@ __global__ __launch_bounds__(64) void rescore_tied_kernel(const DevProblem *__re
         if (near > 1 && my_shard == 0) atomicAdd(tied_rows, 1u);       /* counted once per row, for reporting */
         if (near > 1 && reported != ~0ull && __longlong_as_double((long long)key) <= limit) {
             const DevProblem &P = probs[row % n_probs];
-            const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0};
+            const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0, nullptr};
             const uint64_t index = SEEDED ? 0 : min(reported - first, count - 1);     /* explicit arrays: this shard's own */
             double last, cum;
             eval_strict<SEEDED>(P, P.cp, P.sub, c, reported, index, last, cum, nullptr, snap_none());

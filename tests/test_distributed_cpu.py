@@ -182,3 +182,45 @@ def test_cross_shard_near_ties_are_decided_by_the_strict_model():
     assert key[1] == 4.0 and cand[1] == 100 + 2
     assert key[2] == float("inf") and cand[2] == np.iinfo(np.int64).max
     assert res[0][2] == [(0, 3)] and res[1][2] == [(0, 5)]         # only the tied problem was re-scored, once per shard
+
+
+class _RaggedSolver(_FakeSolver):
+    """shards that stopped at different depths (a node budget, the storage cap or memory can do that: they expand
+    slices of different widths)"""
+
+    def __init__(self, table, completed):
+        super().__init__(table)
+        self.completed = completed
+
+    def solve_tree(self, problem, max_levels, precision, split_level, shard, n_shards):
+        n = self.completed[shard]
+        return _FakeResult(n), [_FakeLevel(*self.table[shard][l]) for l in range(n)]
+
+
+def _ragged_worker(rank, world, port, table, completed, out):
+    from mpc_amd.distributed import solve_tree_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    combined, res, owner = solve_tree_sharded(_RaggedSolver(table, completed), None, 4, split_level=2)
+    out[rank] = (combined, owner)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shards_that_stop_at_different_depths_combine_their_common_levels():
+    """advisor (round 1): the all-gather needs equal shapes, and only the levels EVERY shard completed have a
+    combined winner; a shard that selected nothing at a level (no finite score: ordinal -1) does not take part"""
+    world = 2
+    none = int(np.uint64(0xFFFFFFFFFFFFFFFF).view(np.int64))
+    table = [
+        [(15, 4, 2.5), (270, 33, 1.5), (1000, none & 0xFFFFFFFFFFFFFFFF, float("inf")), (18000, 17, 0.125)],
+        [(15, 4, 2.5), (270, 33, 1.5), (1200, 5, 0.5), (20000, 0, 0.25)],
+    ]
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_ragged_worker, args=(world, _free_port(), table, [4, 3], out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert res[0] == res[1]
+    combined, owner = res[0]
+    assert len(combined) == 3                                              # shard 1 completed only three levels
+    assert combined[2] == (2200, 1000 + 5, _bits(0.5), 1) and owner == 1   # shard 0 selected nothing at level 3
