@@ -14,6 +14,9 @@ with torch.cuda.stream(stream):
     d_last = torch.empty(count, dtype=torch.float64, device="cuda"); d_cum = torch.empty(count, dtype=torch.float64, device="cuda")
     s.upload([prob], [W.SEED])
     N = 20000
+    # the deferred finish (argv[1] == "pipeline"): every solve's finish rides in the next solve's rollout launch, reading
+    # one half of the double-buffered working memory while the rollouts fill the other
+    s.set_pipeline(len(sys.argv) > 1 and sys.argv[1] == "pipeline")
     sink = torch.zeros(2 * N, dtype=torch.int64, device="cuda")
     ref_last = None
     for i in range(N):
@@ -25,10 +28,32 @@ with torch.cuda.stream(stream):
             if ref_last is None: ref_last = cur
             assert torch.equal(cur, ref_last), i
     s.set_winner_sink(None)
+    s.synchronize()                                  # launches the last solve's pending finish
+    s.set_pipeline(False)
     torch.cuda.synchronize()
     w = sink.view(N, 2).cpu().numpy()
     print("config2 x", N, "distinct winners:", len(np.unique(w, axis=0)), w[0], flush=True)
     assert len(np.unique(w, axis=0)) == 1
+    # pipelined, alternating candidate sources and sizes: every kind of hand-over between consecutive launches
+    s.set_pipeline(True)
+    M2 = 6000
+    sink2 = torch.zeros(2 * M2, dtype=torch.int64, device="cuda")
+    kinds = 4
+    for i in range(M2):
+        s.set_winner_sink(sink2[2 * i:2 * i + 2])
+        k = i % kinds
+        if k == 0: s.run_candidates(d_r, d_t, count, M.PREC_FAST)
+        elif k == 1: s.run_seeded(0, count, M.PREC_FAST)
+        elif k == 2: s.run_seeded(1000, 4096, M.PREC_FAST)
+        else: s.run_candidates(d_r, d_t, 30000, M.PREC_FAST)
+    s.set_winner_sink(None)
+    s.synchronize()
+    s.set_pipeline(False)
+    w2 = sink2.view(M2 // kinds, kinds, 2).cpu().numpy()
+    for k in range(kinds):
+        u = np.unique(w2[:, k], axis=0)
+        print("pipelined mix, kind", k, "distinct winners:", len(u), u[0], flush=True)
+        assert len(u) == 1
     # tree, both expansions
     q, _ = W.config1_problem(depth=6)
     for prec in (M.PREC_FAST, M.PREC_F64):
