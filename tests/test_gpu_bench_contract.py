@@ -1,0 +1,58 @@
+"""bench.py's output contract on the GPU: ONE JSON line on stdout carrying the driver's keys, the roofline and (at N=1)
+the CPU baseline; the deferred finish and the two-kernel form choose the same control; the RCCL combine rehearsed with
+one rank reports its ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_keys():
+    d = _bench("--steps", "40", "--warmup", "5")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timed_region_ms"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 5 and d["unit"] == "steps/s" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 65536 * 400 * 40 / (d["timed_region_ms"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 1e6
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and c["same_choice_as_gpu"] is True and c["value"] > 1e6
+    assert d["value"] > 1e11                                       # north_star's floor on one MI355X
+    assert d["p50_solve_latency_ms"] < 5.0                         # ... and its latency bound
+    assert d["config"]["deferred_finish"] is True
+
+
+def test_two_kernel_form_and_rccl_rehearsal_choose_the_same_control():
+    a = _bench("--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-pipeline")
+    b = _bench("--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--force-collective", "--combine-batch", "16")
+    assert a["chosen"]["ordinal"] == b["chosen"]["ordinal"] == b["chosen"]["global_ordinal_after_combine"]
+    assert (a["chosen"]["rudder"], a["chosen"]["throttle"]) == (b["chosen"]["rudder"], b["chosen"]["throttle"])
+    assert b["rccl_ranks"] == 1 and a["rccl_ranks"] is None and b["chosen"]["cross_shard_near_tie_rows"] == 0
+    assert a["config"]["deferred_finish"] is False
+
+
+@pytest.mark.parametrize("workload", ["config4", "config5"])
+def test_other_workloads_run(workload):
+    d = _bench("--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert d["value"] > 1e11 and workload[-1] in d["config"]["workload"].split(":")[0]
