@@ -280,22 +280,29 @@ int         mpc_hip_set_winner_sink(mpc_hip_handle *h, uint64_t *d_dst);
  * (controller.cpp:158-166) across GPUs.  No counterpart in the reference (it has one device: none). */
 int         mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards,
                                    uint32_t n_problems, uint64_t ordinal_stride, uint64_t *d_out);
-/* Stage 1 of the EXACT cross-shard decision for fast-mode runs.  Inside a shard, candidates within MPC_REFINE_REL of
- * the shard's minimum are already decided by the strict model; ACROSS shards the gathered winners carry fast scores
- * (~1.2e-7 relative), which cannot order two shards that close.  d_gathered[shard][row][2] is the all-gather of the
- * copy_winners / winner-sink records (n_rows = solves in the batch x resident problems, row % problems = problem).
- * For every row in which more than one shard lies within MPC_REFINE_REL of the row's minimum and my_shard is one of
- * them, this shard's winner is evaluated once more with the strict model -- from the last run's candidate source:
- * the seed, or the explicit arrays of the last mpc_hip_run_candidates, which must still be valid -- and d_out[row] =
- * (strict score bits, GLOBAL ordinal); every other row passes through with its ordinal made global (+ my_shard *
- * ordinal_stride).  After a second all-gather of d_out, mpc_hip_combine_shards(..., ordinal_stride 0, ...) gives the
- * reference's first strict minimum (controller.cpp:158-166) across GPUs: the true minimum always lies inside the
- * near set, and every record outside it is larger than every strict score inside it.  Strict-mode runs pass through
- * unchanged.  One tiny kernel on the handle's stream.  h_tied_rows (optional; synchronises): rows that had a
- * cross-shard near-tie since the handle was created, as counted by shard 0 (d_gathered == NULL: only read it).
- * No counterpart in the reference. */
-int         mpc_hip_rescore_tied_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
-                                        uint32_t my_shard, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows);
+/* A winner record WITH its controls: [0] score bits, [1] ordinal, then (rudder, throttle) of the winner at every level as
+ * doubles: MPC_WINNER_RECORD_WORDS(depth) uint64 per problem, depth >= the deepest resident problem.  The first form
+ * packs the records of the last run into caller memory (on the stream); the second makes every later run's finish
+ * kernel write its record there itself (NULL: off; replaces a plain winner sink and vice versa), as
+ * mpc_hip_set_winner_sink does for the two-word form. */
+#define MPC_WINNER_RECORD_WORDS(depth) (2 + 2 * (depth))
+int         mpc_hip_copy_winner_records(mpc_hip_handle *h, uint64_t *d_dst, uint32_t depth);
+int         mpc_hip_set_winner_record_sink(mpc_hip_handle *h, uint64_t *d_dst, uint32_t depth);
+/* The EXACT cross-shard decision for fast-mode runs, after ONE all-gather of the winner records.  Inside a shard,
+ * candidates within MPC_REFINE_REL of the shard's minimum are already decided by the strict model; ACROSS shards the
+ * records carry fast scores (~1.2e-7 relative), which cannot order two shards that close.  d_gathered[shard][row]
+ * [MPC_WINNER_RECORD_WORDS(depth)], n_rows = solves in the batch x resident problems (row % problems = problem).  For
+ * every row in which more than one shard lies within MPC_REFINE_REL of the row's minimum, those shards' winners are
+ * evaluated once more with the strict model FROM THE CONTROLS IN THEIR RECORDS -- so every rank can do it for every
+ * shard, all ranks decide alike, and nothing but the gathered buffer and the resident problems is read -- and
+ * d_out[row] = (score bits, global ordinal = gathered ordinal + shard * ordinal_stride) of the lexicographic minimum:
+ * the reference's first strict minimum (controller.cpp:158-166) across GPUs, because the true minimum always lies
+ * inside the near set and every record outside it is larger than every strict score inside it.  Strict-mode runs
+ * reduce to mpc_hip_combine_shards.  One small kernel on the handle's stream (a wave per row, a lane per shard:
+ * n_shards <= 64).  h_tied_rows (optional; synchronises): rows that had a cross-shard near-tie since the handle was
+ * created (d_gathered == NULL: only read it).  No counterpart in the reference. */
+int         mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
+                                         uint32_t depth, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows);
 /* Streams of solves: the deferred finish.  A run is two kernels -- the rollouts with their workgroup argmins, then one
  * small workgroup per problem that reduces them, decides near-ties with the strict model and writes winners, result
  * and trajectory -- and for a 65,536-candidate solve the second one, with its dispatch boundary, is 15 % of the time.

@@ -6,7 +6,7 @@ build ``mpc_problem`` records, and the multi-GPU combine step over torch.distrib
 CPU fallback: if the library is missing or no HIP device is present, calls fail.
 """
 from .binding import (  # noqa: F401
-    LIB_PATH, MpcError, Problem, Result, LevelState, Checkpoint, Model, default_model, TreeLevel, Dubins, Plan, HistorySample, Solver,
+    LIB_PATH, MpcError, Problem, Result, LevelState, Checkpoint, Model, default_model, TreeLevel, Dubins, Plan, HistorySample, Solver, winner_record_words,
     PREC_FAST, PREC_F64, SELECT_LAST_STEP, SELECT_CUMULATIVE, MAX_DEPTH, MAX_SUBSTEPS, REFINE_REL,
     load_library, default_problem, substep_schedule, make_problem, EXPORTED_SYMBOLS,
 )

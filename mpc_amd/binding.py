@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_substep_schedule", "mpc_hip_default_model", "mpc_hip_set_model", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
     "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_history_reset", "mpc_hip_history_update", "mpc_hip_estimate_currents_resident", "mpc_hip_run_seeded", "mpc_hip_run_seeded_static", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
-    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_rescore_tied_shards", "mpc_hip_set_pipeline", "mpc_hip_flush", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
+    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_combine_shards_exact", "mpc_hip_copy_winner_records", "mpc_hip_set_winner_record_sink", "mpc_hip_set_pipeline", "mpc_hip_flush", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
 )
 
 
@@ -140,7 +140,9 @@ def load_library(path=None):
     L.mpc_hip_device_winners.argtypes = [vp, C.POINTER(vp)]
     L.mpc_hip_copy_winners.argtypes = [vp, vp]
     L.mpc_hip_combine_shards.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp]
-    L.mpc_hip_rescore_tied_shards.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64, vp, C.POINTER(C.c_uint32)]
+    L.mpc_hip_combine_shards_exact.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64, vp, C.POINTER(C.c_uint32)]
+    L.mpc_hip_copy_winner_records.argtypes = [vp, vp, C.c_uint32]
+    L.mpc_hip_set_winner_record_sink.argtypes = [vp, vp, C.c_uint32]
     L.mpc_hip_upload_problems_from_plans.argtypes = [vp, PP, C.POINTER(u64), C.POINTER(Plan), dp, C.c_uint32]
     L.mpc_hip_fetch_checkpoints.argtypes = [vp, C.c_uint32, C.POINTER(Checkpoint)]
     L.mpc_hip_estimate_currents.argtypes = [vp, C.POINTER(HistorySample), C.POINTER(C.c_uint32), C.c_uint32, dp, C.c_uint32,
@@ -225,6 +227,11 @@ def make_problem(start, checkpoints, substeps, last=(0.0, 0.0), current=(0.0, 0.
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def winner_record_words(depth):
+    """MPC_WINNER_RECORD_WORDS: (score bits, ordinal) + (rudder, throttle) per level"""
+    return 2 + 2 * int(depth)
 
 
 class Solver:
@@ -376,13 +383,24 @@ class Solver:
     def combine_shards(self, d_gathered, n_shards, n_problems, ordinal_stride, d_out):
         _check(self._L.mpc_hip_combine_shards(self._h, _ptr(d_gathered), n_shards, n_problems, ordinal_stride, _ptr(d_out)))
 
-    def rescore_tied_shards(self, d_gathered, n_shards, n_rows, my_shard, ordinal_stride, d_out, read_count=False):
-        """stage 1 of the exact cross-shard decision (mpc_hip.h); read_count: synchronise and return the number of rows
-        that had a cross-shard near-tie so far (as shard 0 counts them)"""
+    def combine_shards_exact(self, d_gathered, n_shards, n_rows, depth, ordinal_stride, d_out):
+        """the exact cross-shard decision on gathered winner records of winner_record_words(depth) words (mpc_hip.h)"""
+        _check(self._L.mpc_hip_combine_shards_exact(self._h, _ptr(d_gathered), n_shards, n_rows, int(depth), ordinal_stride,
+                                                    _ptr(d_out), None))
+
+    def tied_rows(self):
+        """rows that had a cross-shard near-tie in this handle's combine_shards_exact calls so far; synchronises"""
         n = C.c_uint32(0)
-        _check(self._L.mpc_hip_rescore_tied_shards(self._h, _ptr(d_gathered), n_shards, n_rows, my_shard, ordinal_stride,
-                                                   _ptr(d_out), C.byref(n) if read_count else None))
-        return n.value if read_count else None
+        _check(self._L.mpc_hip_combine_shards_exact(self._h, None, 0, 0, 0, 0, None, C.byref(n)))
+        return n.value
+
+    def copy_winner_records(self, d_dst, depth):
+        """the last run's winners with their controls: winner_record_words(depth) int64 per problem"""
+        _check(self._L.mpc_hip_copy_winner_records(self._h, _ptr(d_dst), int(depth)))
+
+    def set_winner_record_sink(self, d_dst, depth):
+        """runs also write their winner records (with controls) to d_dst (None: off)"""
+        _check(self._L.mpc_hip_set_winner_record_sink(self._h, _ptr(d_dst), int(depth)))
 
     def set_winner_sink(self, d_dst):
         """runs also write their packed winners to d_dst (a device tensor / pointer; None: off)"""

@@ -413,6 +413,12 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     if (nblk64 > 0x7FFFFFFEull) { mpc_set_err("candidate count too large for one launch"); return MPC_ERR_TOO_LARGE; }
     const uint32_t nblk = (uint32_t)nblk64;
 
+    if (h->d_winner_sink && h->winner_sink_words > 2)
+        for (uint32_t p = 0; p < h->n_probs; p++)
+            if (2u + 2u * (uint32_t)h->depth[p] > h->winner_sink_words) {
+                mpc_set_err("the winner record sink is too shallow for a resident problem (mpc_hip_set_winner_record_sink depth)");
+                return MPC_ERR_INVALID;
+            }
     /* which half of the working memory this run writes: the other one may still be read by a pending finish */
     const bool pipelined = h->pipeline && !use_static;
     if (h->pending && !pipelined) { if (int s = flush_pending(h)) return s; }
@@ -509,7 +515,8 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     HIP_TRY(hipGetLastError());
     /* this run's finish: pending (pipeline) or launched right away */
     h->pend = FinishArgs{h->d_probs, d_rud, d_thr, first, count, selection, fast, (int)uniform, rel, nblk, cpb,
-                         d_pkey, d_pord, d_pcnt, d_keys, d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->d_results};
+                         d_pkey, d_pord, d_pcnt, d_keys, d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->winner_sink_words, 0u,
+                         h->d_results};
     h->pending = true; h->pend_seeded = seeded; h->pend_n_probs = h->n_probs; h->pend_half = half;
     h->pend_slot = slot; h->pend_timed = timed;
     if (!pipelined) { if (int s = flush_pending(h)) return s; }
@@ -660,6 +667,31 @@ extern "C" int mpc_hip_set_winner_sink(mpc_hip_handle *h, uint64_t *d_dst)
 {
     if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
     h->d_winner_sink = d_dst;
+    h->winner_sink_words = 2;
+    return MPC_OK;
+}
+
+extern "C" int mpc_hip_set_winner_record_sink(mpc_hip_handle *h, uint64_t *d_dst, uint32_t depth)
+{
+    if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
+    if (depth < 1 || depth > MPC_MAX_DEPTH) { mpc_set_err("winner record depth out of range [1, MPC_MAX_DEPTH]"); return MPC_ERR_INVALID; }
+    h->d_winner_sink = d_dst;
+    h->winner_sink_words = MPC_WINNER_RECORD_WORDS(depth);
+    return MPC_OK;
+}
+
+extern "C" int mpc_hip_copy_winner_records(mpc_hip_handle *h, uint64_t *d_dst, uint32_t depth)
+{
+    if (!h || !d_dst || h->n_probs == 0) { mpc_set_err("copy_winner_records: NULL argument or nothing uploaded"); return MPC_ERR_INVALID; }
+    if (depth < 1 || depth > MPC_MAX_DEPTH) { mpc_set_err("winner record depth out of range [1, MPC_MAX_DEPTH]"); return MPC_ERR_INVALID; }
+    if (!h->ran) { mpc_set_err("copy_winner_records: nothing has run since the last upload"); return MPC_ERR_INVALID; }
+    for (uint32_t p = 0; p < h->n_probs; p++)
+        if ((uint32_t)h->depth[p] > depth) { mpc_set_err("copy_winner_records: a resident problem is deeper than the record"); return MPC_ERR_INVALID; }
+    if (int s = mpc_use_device(h)) return s;
+    if (int s = flush_pending(h)) return s;
+    hipLaunchKernelGGL(pack_records_kernel, dim3(h->n_probs), dim3(64), 0, h->stream, h->d_results, h->d_winners, h->d_probs,
+                       (uint32_t)MPC_WINNER_RECORD_WORDS(depth), d_dst);
+    HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
 
@@ -683,8 +715,8 @@ extern "C" int mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathe
     return MPC_OK;
 }
 
-extern "C" int mpc_hip_rescore_tied_shards(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
-                                           uint32_t my_shard, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows)
+extern "C" int mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
+                                            uint32_t depth, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows)
 {
     if (h && !d_gathered && h_tied_rows) {           /* read the counter only */
         if (int s = mpc_use_device(h)) return s;
@@ -695,25 +727,22 @@ extern "C" int mpc_hip_rescore_tied_shards(mpc_hip_handle *h, const uint64_t *d_
         memcpy(h_tied_rows, h->h_pair, sizeof(uint32_t));
         return MPC_OK;
     }
-    if (!h || !d_gathered || !d_out || n_shards == 0 || n_rows == 0 || my_shard >= n_shards) {
-        mpc_set_err("rescore_tied_shards: NULL, empty or out-of-range argument"); return MPC_ERR_INVALID;
-    }
-    if (!h->ran) { mpc_set_err("rescore_tied_shards: nothing has run since the last upload"); return MPC_ERR_INVALID; }
-    if (n_rows % h->n_probs) { mpc_set_err("rescore_tied_shards: n_rows is not a multiple of the resident problems"); return MPC_ERR_INVALID; }
+    if (!h || !d_gathered || !d_out || n_shards == 0 || n_rows == 0) { mpc_set_err("combine_shards_exact: NULL or empty argument"); return MPC_ERR_INVALID; }
+    if (n_shards > 64) { mpc_set_err("combine_shards_exact: more than 64 shards"); return MPC_ERR_TOO_LARGE; }
+    if (depth < 1 || depth > MPC_MAX_DEPTH) { mpc_set_err("winner record depth out of range [1, MPC_MAX_DEPTH]"); return MPC_ERR_INVALID; }
+    if (h->n_probs == 0 || !h->ran) { mpc_set_err("combine_shards_exact: nothing has run on the resident problems"); return MPC_ERR_INVALID; }
+    if (n_rows % h->n_probs) { mpc_set_err("combine_shards_exact: n_rows is not a multiple of the resident problems"); return MPC_ERR_INVALID; }
+    for (uint32_t p = 0; p < h->n_probs; p++)
+        if ((uint32_t)h->depth[p] > depth) { mpc_set_err("combine_shards_exact: a resident problem is deeper than the records"); return MPC_ERR_INVALID; }
     if (int s = mpc_use_device(h)) return s;
     if (!h->d_tied_rows) {
         HIP_TRY(hipMalloc(&h->d_tied_rows, sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(h->d_tied_rows, 0, sizeof(uint32_t), h->stream));
     }
-    const dim3 grid((n_rows + 63) / 64), blk(64);
-    /* only fast-mode winners need it: strict-mode records already carry the reference's arithmetic (negative: pass through) */
+    /* only fast-mode winners need re-scoring: strict-mode records already carry the reference's arithmetic */
     const double rel = h->last_precision == MPC_PREC_FAST ? MPC_REFINE_REL : -1.0;
-    if (h->last_seeded)
-        hipLaunchKernelGGL(rescore_tied_kernel<true>, grid, blk, 0, h->stream, h->d_probs, h->n_probs, nullptr, nullptr, h->last_first,
-                           h->last_count, h->last_selection, d_gathered, n_shards, n_rows, my_shard, ordinal_stride, rel, d_out, h->d_tied_rows);
-    else
-        hipLaunchKernelGGL(rescore_tied_kernel<false>, grid, blk, 0, h->stream, h->d_probs, h->n_probs, h->last_rud, h->last_thr, h->last_first,
-                           h->last_count, h->last_selection, d_gathered, n_shards, n_rows, my_shard, ordinal_stride, rel, d_out, h->d_tied_rows);
+    hipLaunchKernelGGL(combine_exact_kernel, dim3(n_rows), dim3(64), 0, h->stream, h->d_probs, h->n_probs, h->last_selection, d_gathered,
+                       n_shards, n_rows, (uint32_t)MPC_WINNER_RECORD_WORDS(depth), ordinal_stride, rel, d_out, h->d_tied_rows);
     HIP_TRY(hipGetLastError());
     if (h_tied_rows) {                       /* optional read-back (synchronises): rows with a cross-shard near-tie so far */
         HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_tied_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));

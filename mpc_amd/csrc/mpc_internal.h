@@ -84,6 +84,7 @@ struct FinishArgs {
     double *snap_base;
     int snap_depth;
     uint64_t *winners, *sink;
+    uint32_t sink_words, pad;
     DevResult *results;
 };
 /* what K1 writes and K2 reads, twice (mpc_hip_set_pipeline): half 0's workgroup triples are h->d_pkey/d_pord/d_pcnt,
@@ -113,6 +114,7 @@ struct mpc_hip_handle {
     DevResult *d_results = nullptr, *h_results = nullptr;       /* h_results pinned */
     uint64_t *d_winners = nullptr;
     uint64_t *d_winner_sink = nullptr;                          /* caller memory that runs also write the winners to */
+    uint32_t winner_sink_words = 2;                             /* 2, or 2 + 2 * depth (records with controls) */
     uint32_t *d_list_count = nullptr;                           /* per-problem scratch word (tree trace cursor) */
     uint64_t *d_pkey = nullptr, *d_pord = nullptr;              /* K1 workgroup triples */
     uint32_t *d_pcnt = nullptr;
@@ -128,7 +130,7 @@ struct mpc_hip_handle {
     void *d_static_scratch = nullptr;                           /* this device's copy of scratch[] (mpc_hip.hip), not owned */
 
     const float *last_rud = nullptr, *last_thr = nullptr;       /* the last run's explicit control arrays (caller memory) */
-    uint32_t *d_tied_rows = nullptr;                            /* counter of mpc_hip_rescore_tied_shards */
+    uint32_t *d_tied_rows = nullptr;                            /* counter of mpc_hip_combine_shards_exact */
     uint64_t last_count = 0, last_first = 0;
     int last_precision = 0, last_selection = 0, last_seeded = 0;
     bool ran = false;

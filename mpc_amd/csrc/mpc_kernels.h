@@ -282,6 +282,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
     double *__restrict__ snap_base = A.snap_base;
     const int snap_depth = A.snap_depth;
     uint64_t *__restrict__ winners = A.winners, *__restrict__ sink = A.sink;
+    const uint32_t sw = A.sink_words;              /* 2: (score bits, ordinal); 2 + 2 * depth: + the winner's controls */
     DevResult *__restrict__ results = A.results;
     uint64_t *red = small, *s_win = small + 8;
     uint32_t &s_n = *(uint32_t *)(small + 10);
@@ -380,7 +381,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
         if (threadIdx.x == 0) {
             R.key_bits = KEY_INF; R.ordinal = win; R.best_last = 0; R.best_cum = 0; R.refined = 0; R.overflow = overflow;
             winners[2 * p] = KEY_INF; winners[2 * p + 1] = win;
-            if (sink) { sink[2 * p] = KEY_INF; sink[2 * p + 1] = win; }
+            if (sink) { sink[(size_t)p * sw] = KEY_INF; sink[(size_t)p * sw + 1] = win; }
         }
         return;
     }
@@ -436,6 +437,10 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
                 R.traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog, clampd(r, -1, 1), clampd(t, 0, 1), cum};
             }
             if (l == P.depth - 1) { s_tail[0] = last; s_tail[1] = cum; }
+            if (sink && sw > 2) {                  /* the winner's controls travel with its record (mpc_hip_combine_shards_exact) */
+                sink[(size_t)p * sw + 2 + 2 * l] = (uint64_t)__double_as_longlong(clampd(r, -1, 1));
+                sink[(size_t)p * sw + 3 + 2 * l] = (uint64_t)__double_as_longlong(clampd(t, 0, 1));
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -445,7 +450,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
             R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
             R.refined = 0; R.overflow = overflow;
             winners[2 * p] = kb; winners[2 * p + 1] = win;
-            if (sink) { sink[2 * p] = kb; sink[2 * p + 1] = win; }
+            if (sink) { sink[(size_t)p * sw] = kb; sink[(size_t)p * sw + 1] = win; }
         }
     } else if (threadIdx.x == 0) {
         double last = 0, cum = 0;
@@ -457,7 +462,14 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
         R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
         R.refined = n > 1 ? n : 0; R.overflow = overflow;
         winners[2 * p] = kb; winners[2 * p + 1] = win;
-        if (sink) { sink[2 * p] = kb; sink[2 * p + 1] = win; }
+        if (sink) {
+            sink[(size_t)p * sw] = kb; sink[(size_t)p * sw + 1] = win;
+            if (sw > 2)
+                for (int l = 0; l < P.depth; l++) {
+                    sink[(size_t)p * sw + 2 + 2 * l] = (uint64_t)__double_as_longlong(R.traj[l + 1].rudder);
+                    sink[(size_t)p * sw + 3 + 2 * l] = (uint64_t)__double_as_longlong(R.traj[l + 1].throttle);
+                }
+        }
     }
 }
 
@@ -591,48 +603,67 @@ __global__ __launch_bounds__(256) void combine_shards_kernel(const uint64_t *__r
     out[2 * p] = k; out[2 * p + 1] = o;
 }
 
-/* multi-GPU, fast mode: stage 1 of the EXACT cross-shard decision.  The gathered winners carry fast scores (good to
- * ~1.2e-7 relative), so two shards whose winners lie within refine_rel of each other cannot be ordered by them.  A lane
- * per row (solve x problem): where more than one shard lies within refine_rel of the row's minimum and THIS shard is
- * one of them, its winner is evaluated once more with the strict model (the reference's arithmetic) and (strict score
- * bits, global ordinal) replaces its record; otherwise the record passes through with its ordinal made global.  After
- * a second all-gather of these records combine_shards_kernel (stride 0) yields the reference's first strict minimum:
- * the true minimum is always inside the near set (refine_rel is 9x the fast model's error), and every record outside
- * it is larger than every strict score inside it.  Rare path: reads the problem from global memory, no staging. */
-template <bool SEEDED>
-__global__ __launch_bounds__(64) void rescore_tied_kernel(const DevProblem *__restrict__ probs, uint32_t n_probs,
-                                                          const float *__restrict__ rud, const float *__restrict__ thr,
-                                                          uint64_t first, uint64_t count, int selection,
-                                                          const uint64_t *__restrict__ gathered, uint32_t n_shards,
-                                                          uint32_t n_rows, uint32_t my_shard, uint64_t ordinal_stride,
-                                                          double refine_rel, uint64_t *__restrict__ out,
-                                                          uint32_t *__restrict__ tied_rows)
+/* A winner record with its controls: [0] score bits, [1] ordinal, then (rudder, throttle) per level as doubles --
+ * 2 + 2 * depth words.  pack_records_kernel builds them from the results of the last run (mpc_hip_copy_winner_records);
+ * the finish kernel writes the same layout into a record sink (mpc_hip_set_winner_record_sink). */
+__global__ __launch_bounds__(64) void pack_records_kernel(const DevResult *__restrict__ results, const uint64_t *__restrict__ winners,
+                                                          const DevProblem *__restrict__ probs, uint32_t words, uint64_t *__restrict__ dst)
 {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
-    uint64_t kmin = ~0ull;
-    for (uint32_t s = 0; s < n_shards; s++) kmin = min(kmin, gathered[((uint64_t)s * n_rows + row) * 2]);
-    const uint64_t *mine = gathered + ((uint64_t)my_shard * n_rows + row) * 2;
-    uint64_t key = mine[0];
-    const uint64_t reported = mine[1];             /* as K1 numbered it: first + index, the ordinal its controls came from */
-    const uint64_t ordinal = reported == ~0ull ? ~0ull : reported + (uint64_t)my_shard * ordinal_stride;
+    const uint32_t p = blockIdx.x, l = threadIdx.x;
+    uint64_t *rec = dst + (size_t)p * words;
+    if (l == 0) { rec[0] = winners[2 * p]; rec[1] = winners[2 * p + 1]; }
+    if ((int)l < probs[p].depth && 3 + 2 * l < words) {
+        rec[2 + 2 * l] = (uint64_t)__double_as_longlong(results[p].traj[l + 1].rudder);
+        rec[3 + 2 * l] = (uint64_t)__double_as_longlong(results[p].traj[l + 1].throttle);
+    }
+}
+
+/* multi-GPU: the EXACT cross-shard decision in one kernel, after ONE all-gather of the winner records.  Inside a shard,
+ * candidates within MPC_REFINE_REL of the shard's minimum are already decided by the strict model; ACROSS shards the
+ * records carry fast scores (good to ~1.2e-7 relative), which cannot order two shards that close.  One wave per row
+ * (solve x problem), one lane per shard: where more than one shard lies within refine_rel of the row's minimum, those
+ * lanes evaluate their shard's winner once more with the strict model -- the reference's arithmetic -- FROM THE CONTROLS
+ * IN ITS RECORD, so every rank can do it for every shard and all ranks decide alike without a second exchange; then the
+ * lexicographic (score bits, global ordinal) minimum: the reference's first strict minimum (controller.cpp:158-166),
+ * because the true minimum always lies inside the near set (refine_rel is 9x the fast model's error) and every record
+ * outside it is larger than every strict score inside it.  refine_rel < 0 (strict-mode runs): plain minimum. */
+__global__ __launch_bounds__(64) void combine_exact_kernel(const DevProblem *__restrict__ probs, uint32_t n_probs, int selection,
+                                                           const uint64_t *__restrict__ gathered, uint32_t n_shards,
+                                                           uint32_t n_rows, uint32_t words, uint64_t ordinal_stride,
+                                                           double refine_rel, uint64_t *__restrict__ out,
+                                                           uint32_t *__restrict__ tied_rows)
+{
+    const uint32_t row = blockIdx.x, s = threadIdx.x;
+    const bool mine = s < n_shards;
+    const uint64_t *rec = gathered + ((size_t)(mine ? s : 0) * n_rows + row) * words;
+    uint64_t key = mine ? rec[0] : ~0ull;
+    const uint64_t reported = mine ? rec[1] : ~0ull;
+    const uint64_t ordinal = reported == ~0ull ? ~0ull : reported + (uint64_t)s * ordinal_stride;
+    uint64_t kmin = key;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) kmin = min(kmin, (uint64_t)__shfl_xor((unsigned long long)kmin, m, 64));
     if (refine_rel >= 0.0 && kmin < KEY_INF) {
         const double m = __longlong_as_double((long long)kmin);
-        const double limit = m + m * refine_rel;
-        uint32_t near = 0;
-        for (uint32_t s = 0; s < n_shards; s++)
-            near += __longlong_as_double((long long)gathered[((uint64_t)s * n_rows + row) * 2]) <= limit;
-        if (near > 1 && my_shard == 0) atomicAdd(tied_rows, 1u);       /* counted once per row, for reporting */
-        if (near > 1 && reported != ~0ull && __longlong_as_double((long long)key) <= limit) {
+        const bool near = mine && reported != ~0ull && __longlong_as_double((long long)key) <= m + m * refine_rel;
+        const uint32_t n_near = (uint32_t)__popcll(__ballot(near));
+        if (n_near > 1 && s == 0) atomicAdd(tied_rows, 1u);            /* for reporting */
+        if (n_near > 1 && near) {
             const DevProblem &P = probs[row % n_probs];
-            const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t, nullptr, 0, nullptr};
-            const uint64_t index = SEEDED ? 0 : min(reported - first, count - 1);     /* explicit arrays: this shard's own */
-            double last, cum;
-            eval_strict<SEEDED>(P, P.cp, P.sub, c, reported, index, last, cum, nullptr, snap_none());
+            const Weights w{P.wd, P.wh, P.ws};
+            const Model M = P.model;
+            Veh v{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0};
+            double last = 0, cum = 0;
+            for (int l = 0; l < P.depth && 3 + 2 * l < (int)words; l++) {
+                const double r = __longlong_as_double((long long)rec[2 + 2 * l]), t = __longlong_as_double((long long)rec[3 + 2 * l]);
+                last = strict_level_and_score<false>(P, M, w, P.cp, P.sub, P.sub, l, r, t, v);
+                cum += last;
+            }
             key = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
         }
     }
-    out[2 * (uint64_t)row] = key; out[2 * (uint64_t)row + 1] = ordinal;
+    uint64_t k = key, o = ordinal;
+    wave_argmin(k, o);
+    if (s == 0) { out[2 * (size_t)row] = k; out[2 * (size_t)row + 1] = o; }
 }
 
 /* single explicit control sequence (double precision controls), mpc_hip_rollout */

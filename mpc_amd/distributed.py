@@ -12,6 +12,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .binding import winner_record_words
+
 I64_MAX = np.iinfo(np.int64).max
 
 
@@ -76,23 +78,24 @@ class ShardCombiner:
         combiner.begin() ; solver.run_*(...) ; combiner.submit()        # per solve
         key_bits, ordinal = combiner.flush()         # after the last one: every submitted solve is combined
 
-    begin() points the solver's winner sink (mpc_hip_set_winner_sink) at the next row of a batch buffer, so the finish
-    kernel itself deposits this rank's winners there (no device copy per solve); every `batch` solves ONE asynchronous
-    all-gather moves batch x 16 bytes per problem and rank (instead of two dependent 8-byte all-reduces per solve:
-    fewer, larger collectives).  A batch then moves one stage per later batch, so that every collective's latency
-    hides behind a batch of rollouts:
-        stage 1  all-gather of the fast winners in flight
-        stage 2  (exact) mpc_hip_rescore_tied_shards -- shards within MPC_REFINE_REL of a row's minimum re-score their
-                 winner with the strict model -- and a second asynchronous all-gather of those records
-        done     mpc_hip_combine_shards (one tiny kernel): the reference's first strict minimum across the GPUs
-    exact=False combines the fast keys after stage 1 (two shards whose winners lie within the fast model's ~1e-7 error
-    may then resolve differently from the reference).  No host synchronisation anywhere.
-    ordinal_stride: what separates the shards' local ordinals (0 when the shards were run with their first_ordinal).
-    The rescore uses the resident problems and the last run's candidate source: flush() before either changes.
+    begin() points the solver's winner sink at the next row of a batch buffer, so the finish kernel itself deposits
+    this rank's winner records there (no device copy per solve); every `batch` solves ONE asynchronous all-gather moves
+    the batch (instead of two dependent 8-byte all-reduces per solve: fewer, larger collectives), and its latency hides
+    behind the next batch of rollouts; then one small kernel decides:
+        exact=True   the records carry the winners' controls (mpc_hip_set_winner_record_sink, 16 + 16 * depth bytes
+                     per problem) and mpc_hip_combine_shards_exact re-scores, with the strict model, the winners of
+                     shards within MPC_REFINE_REL of a row's minimum: the reference's first strict minimum across the
+                     GPUs, from ONE exchange
+        exact=False  16-byte records, mpc_hip_combine_shards on the fast keys (two shards whose winners lie within the
+                     fast model's ~1e-7 error may then resolve differently from the reference)
+    No host synchronisation anywhere.  ordinal_stride: what separates the shards' local ordinals (0 when the shards
+    were run with their first_ordinal).  depth: levels per record, >= the deepest resident problem.  The exact decision
+    reads the resident problems: flush() before they change.
     flush() returns the combined (score bits, global ordinal) of the LAST solve; `results` holds the last batch.
     """
 
-    def __init__(self, solver, n_problems, ordinal_stride=0, group=None, batch=16, slots=3, always=False, exact=True):
+    def __init__(self, solver, n_problems, ordinal_stride=0, group=None, batch=16, slots=3, always=False, exact=True,
+                 depth=None):
         self.solver, self.P, self.stride, self.group = solver, int(n_problems), int(ordinal_stride), group
         self.B = int(batch)
         on = dist.is_available() and dist.is_initialized()
@@ -100,135 +103,121 @@ class ShardCombiner:
         self.rank = dist.get_rank(group) if on else 0
         self.collective = on and (always or self.world > 1)
         self.exact = bool(exact) and self.collective
+        if self.exact and depth is None:
+            raise ValueError("ShardCombiner(exact=True) needs depth (levels per winner record)")
+        self.depth = int(depth) if self.exact else 0
+        self.W = winner_record_words(self.depth) if self.exact else 2
         dev = torch.device("cuda", solver.device)
-        row = 2 * self.P
+        row = self.W * self.P
         z = lambda n: torch.zeros(n, dtype=torch.int64, device=dev)
         self.win = [z(self.B * row) for _ in range(slots)]
         for w in self.win:                   # rows never written read "nothing selected" (+inf bits, ordinal -1), not score 0
-            w.view(-1, 2)[:, 0] = 0x7FF0000000000000
-            w.view(-1, 2)[:, 1] = -1
+            w.view(-1, self.W)[:, 0] = 0x7FF0000000000000
+            w.view(-1, self.W)[:, 1] = -1
         torch.cuda.synchronize(dev)          # the solver's stream may not be torch's
-        self.gathered = [z(self.B * row * self.world) for _ in range(slots)]
-        self.rescored = [z(self.B * row) if self.exact else None for _ in range(slots)]
-        self.gathered2 = [z(self.B * row * self.world) if self.exact else None for _ in range(slots)]
-        self.results = z(self.B * row)
+        self.gathered = [z(self.B * row * self.world) if self.collective else None for _ in range(slots)]
+        self.results = z(self.B * 2 * self.P)
         self.work = [None] * slots
-        self.stage = [0] * slots             # 0 = free / filling, 1 = first all-gather issued, 2 = second all-gather issued
         self.pending = []                    # slots whose batch is not combined yet, oldest first
         self.slot, self.fill, self.last = 0, 0, None
 
-    def _wait(self, r):
+    def _combine(self, r):
+        rows = self.B * self.P
         if self.work[r] is not None:
             self.work[r].wait()              # the current stream waits for the collective (no host sync)
             self.work[r] = None
-
-    def _advance(self, r):
-        """move slot r's batch one stage on; -> True when it is combined"""
-        rows = self.B * self.P
-        self._wait(r)
-        if self.stage[r] == 1 and self.exact:
-            self.solver.rescore_tied_shards(self.gathered[r], self.world, rows, self.rank, self.stride, self.rescored[r])
-            self.work[r] = dist.all_gather_into_tensor(self.gathered2[r], self.rescored[r], group=self.group, async_op=True)
-            self.stage[r] = 2
-            return False
-        if self.stage[r] == 2:
-            self.solver.combine_shards(self.gathered2[r], self.world, rows, 0, self.results)
+        if self.exact:
+            self.solver.combine_shards_exact(self.gathered[r], self.world, rows, self.depth, self.stride, self.results)
         else:
             src = self.gathered[r] if self.collective else self.win[r]
             self.solver.combine_shards(src, self.world if self.collective else 1, rows, self.stride, self.results)
-        self.stage[r] = 0
-        return True
-
-    def _drain(self, r):
-        while not self._advance(r):
-            pass
         self.pending.remove(r)
 
     def tied_rows(self):
-        """rows (solve x problem) that had a cross-shard near-tie so far, as shard 0 counts them; synchronises"""
-        return self.solver.rescore_tied_shards(None, 0, 0, 0, 0, None, read_count=True) if self.exact else 0
+        """rows (solve x problem) that had a cross-shard near-tie so far; synchronises"""
+        return self.solver.tied_rows() if self.exact else 0
 
     def _close_batch(self):
         r = self.slot
         self.solver.flush()                  # a deferred finish (mpc_hip_set_pipeline) deposits the batch's last row now
         if self.collective:
             self.work[r] = dist.all_gather_into_tensor(self.gathered[r], self.win[r], group=self.group, async_op=True)
-        self.stage[r] = 1
         self.pending.append(r)
         self.last = (r, self.fill - 1)
         self.slot, self.fill = (r + 1) % len(self.win), 0
 
     def _row(self):
         if self.fill == 0 and self.slot in self.pending:      # about to overwrite a batch that is not combined yet
-            while self.pending and self.pending[0] != self.slot:
-                self._drain(self.pending[0])
-            self._drain(self.slot)
-        row = 2 * self.P
+            while self.slot in self.pending:
+                self._combine(self.pending[0])
+        row = self.W * self.P
         return self.win[self.slot][self.fill * row:(self.fill + 1) * row]
+
+    def _point_sink(self, dst):
+        if self.exact:
+            self.solver.set_winner_record_sink(dst, self.depth)
+        else:
+            self.solver.set_winner_sink(dst)
 
     def begin(self):
         """before the run whose winners go into the next row"""
-        self.solver.set_winner_sink(self._row())
+        self._point_sink(self._row())
         self._begun = True
 
     def submit(self):
         """after the run"""
         if not getattr(self, "_begun", False):        # begin() was skipped: a device copy of the winners instead
-            self.solver.copy_winners(self._row())
+            if self.exact:
+                self.solver.copy_winner_records(self._row(), self.depth)
+            else:
+                self.solver.copy_winners(self._row())
         self._begun = False
         self.fill += 1
         if self.fill == self.B:
             older = list(self.pending)
             self._close_batch()
-            for r in older:                           # batches older than the one just closed move one stage on
-                if self._advance(r):
-                    self.pending.remove(r)
+            for r in older:                           # the batches before the one just closed: their gather has had a batch of rollouts
+                self._combine(r)
 
     def flush(self):
-        self.solver.set_winner_sink(None)
+        self._point_sink(None)
         if self.fill:
             self._close_batch()
         while self.pending:
-            self._drain(self.pending[0])
+            self._combine(self.pending[0])
         if self.last is None:
             return None
         o = self.results.view(self.B, self.P, 2)[self.last[1]]
         return o[:, 0], o[:, 1]
 
 
-def combine_shards_exact(solvers, gathered, ordinal_stride=0):
-    """The exact cross-shard decision with every shard in THIS process (rehearsal of N GPUs on one: solvers[s] is the
-    handle that ran shard s): gathered int64 [n_shards, rows, 2] on the device (the copy_winners records, shard-local
-    ordinals as the runs reported them) -> int64 [rows, 2] = (strict-decided score bits, global ordinal).  The same
-    two C-ABI calls per shard as ShardCombiner makes across processes, with torch.stack in place of the all-gathers."""
-    n_shards, rows = int(gathered.shape[0]), int(gathered.shape[1])
-    g = gathered.contiguous()
+def combine_shards_exact(solver, records, depth, ordinal_stride=0):
+    """The exact cross-shard decision with every shard in THIS process (rehearsal of N GPUs on one): records int64
+    [n_shards, rows, winner_record_words(depth)] on the device (copy_winner_records of each shard's run, shard-local
+    ordinals as the runs reported them; torch.stack in place of the all-gather) -> int64 [rows, 2] = (strict-decided
+    score bits, global ordinal).  solver: any handle holding the problems (every rank holds them all)."""
+    n_shards, rows = int(records.shape[0]), int(records.shape[1])
+    g = records.contiguous()
     torch.cuda.synchronize()
-    stage1 = torch.zeros_like(g)
-    for s, solver in enumerate(solvers):
-        solver.rescore_tied_shards(g, n_shards, rows, s, ordinal_stride, stage1[s])
-        solver.synchronize()
     out = torch.zeros((rows, 2), dtype=torch.int64, device=g.device)
-    solvers[0].combine_shards(stage1, n_shards, rows, 0, out)
-    solvers[0].synchronize()
+    solver.combine_shards_exact(g, n_shards, rows, depth, ordinal_stride, out)
+    solver.synchronize()
     return out
 
 
-def combine_winners_exact_device(solver, winners, ordinal_stride=0, group=None):
-    """One solve, every rank its own GPU: all-gather of the packed winners -> mpc_hip_rescore_tied_shards -> all-gather
-    -> mpc_hip_combine_shards, all stream-ordered on the device.  winners: int64 [P, 2] device tensor as
-    mpc_hip_copy_winners leaves it.  -> int64 [P, 2] (score bits, global ordinal), identical on every rank."""
-    w = winners.view(-1, 2).contiguous()
-    P = w.shape[0]
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    gathered = torch.empty((world, P, 2), dtype=torch.int64, device=w.device)
-    dist.all_gather_into_tensor(gathered.view(-1), w.view(-1), group=group)
-    mine = torch.empty((P, 2), dtype=torch.int64, device=w.device)
-    solver.rescore_tied_shards(gathered, world, P, rank, ordinal_stride, mine)
-    gathered2 = torch.empty((world, P, 2), dtype=torch.int64, device=w.device)
-    dist.all_gather_into_tensor(gathered2.view(-1), mine.view(-1), group=group)
-    out = torch.empty((P, 2), dtype=torch.int64, device=w.device)
-    solver.combine_shards(gathered2, world, P, 0, out)
+def combine_winners_exact_device(solver, depth, ordinal_stride=0, group=None):
+    """One solve, every rank its own GPU: the winner records of the solver's last run -> ONE all-gather ->
+    mpc_hip_combine_shards_exact, all stream-ordered on the device (the solver must run on torch's current stream).
+    -> int64 [P, 2] (score bits, global ordinal), identical on every rank."""
+    P, W = solver._n_problems, winner_record_words(depth)
+    dev = torch.device("cuda", solver.device)
+    world = dist.get_world_size(group)
+    mine = torch.empty(P * W, dtype=torch.int64, device=dev)
+    solver.copy_winner_records(mine, depth)
+    gathered = torch.empty(world * P * W, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    out = torch.empty((P, 2), dtype=torch.int64, device=dev)
+    solver.combine_shards_exact(gathered, world, P, depth, ordinal_stride, out)
     return out
 
 

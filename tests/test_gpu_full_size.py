@@ -93,7 +93,7 @@ def test_config4_the_whole_16M_set_as_8_shards_and_as_one_launch():
     """BASELINE config 4 at its real size: 2^24 device-generated candidates x 30 s x 20 substeps.  The 8 contiguous
     shards a node's 8 GPUs would hold run one after the other on this GPU (one handle each, as one process per GPU
     holds one), their packed winners are gathered and combined (a) by mpc_hip_combine_shards on the fast keys and (b)
-    by the exact decision (mpc_hip_rescore_tied_shards -> combine); both must be the winner of ONE 2^24-candidate
+    by the exact decision (winner records with controls -> mpc_hip_combine_shards_exact); both must be the winner of ONE 2^24-candidate
     launch, whose costs the shards reproduce bit for bit, and a strided 1/4096 oracle sample over the whole ordinal
     range is within 1e-5 and never better than the winner (controller.cpp:158-166: first strict minimum)."""
     torch = _torch()
@@ -108,6 +108,7 @@ def test_config4_the_whole_16M_set_as_8_shards_and_as_one_launch():
         assert res_all.status == 0 and res_all.evaluated == total and res_all.rollout_steps == total * 30 * 20
         last_sh = torch.empty(total, dtype=torch.float64, device="cuda")
         wins = torch.zeros((world, 1, 2), dtype=torch.int64, device="cuda")
+        recs = torch.zeros((world, 1, M.winner_record_words(30)), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         for s, solver in enumerate(shards):
             first, count = shard_range(total, s, world)
@@ -115,6 +116,7 @@ def test_config4_the_whole_16M_set_as_8_shards_and_as_one_launch():
             solver.upload([p], [W.SEED])
             solver.run_seeded(first, count, M.PREC_FAST, M.SELECT_LAST_STEP, last_sh[first:first + count], None)
             solver.copy_winners(wins[s])
+            solver.copy_winner_records(recs[s], 30)
             r = solver.fetch()[0]
             assert r.status == 0 and first <= r.best_ordinal < first + count
         assert torch.equal(last_sh.view(torch.int64), last_all.view(torch.int64))         # every candidate, bit for bit
@@ -122,7 +124,8 @@ def test_config4_the_whole_16M_set_as_8_shards_and_as_one_launch():
         torch.cuda.synchronize()
         shards[0].combine_shards(wins, world, 1, 0, out_fast)
         shards[0].synchronize()
-        out_exact = combine_shards_exact(shards, wins, 0)
+        assert torch.equal(recs[:, :, :2], wins)
+        out_exact = combine_shards_exact(shards[3], recs, 30, 0)
         best = int(res_all.best_ordinal)
         assert int(out_fast[0, 1]) == best and int(out_exact[0, 1]) == best
         key = int(np.float64(res_all.best_last).view(np.int64))
@@ -171,22 +174,24 @@ def test_cross_shard_near_tie_is_decided_by_the_strict_model():
                       torch.tensor(t.astype(np.float32), device="cuda").contiguous())
         for first_shard, second_shard in ((b, a), (a, b)):
             wins = torch.zeros((2, 1, 2), dtype=torch.int64, device="cuda")
+            recs = torch.zeros((2, 1, M.winner_record_words(20)), dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
             for s, (solver, o) in enumerate(((s0, first_shard), (s1, second_shard))):
                 res = solver.eval_candidates(p, ctl[o][0], ctl[o][1], 1, M.PREC_FAST)
                 assert res.best_ordinal == 0 and res.best_last == fast[o]                # one candidate: local ordinal 0
                 solver.copy_winners(wins[s])
+                solver.copy_winner_records(recs[s], 20)
                 solver.synchronize()
             out_fast = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
             s0.combine_shards(wins, 2, 1, 1, out_fast)                                   # ordinal stride 1: global = shard index
             s0.synchronize()
-            out_exact = combine_shards_exact([s0, s1], wins, 1)
+            out_exact = combine_shards_exact(s0, recs, 20, 1)
             shard_of = {first_shard: 0, second_shard: 1}
             assert int(out_fast[0, 1]) == shard_of[b]                                    # the fast keys prefer b ...
             assert int(out_exact[0, 1]) == shard_of[a]                                   # ... the reference's arithmetic a
             assert int(out_exact[0, 0]) == int(np.float64(strict[a]).view(np.int64))
-        assert s0.rescore_tied_shards(None, 0, 0, 0, 0, None, read_count=True) == 2      # both rounds had a near-tie row
+        assert s0.tied_rows() == 2                                                       # both rounds had a near-tie row
     finally:
         s0.close()
         s1.close()

@@ -272,8 +272,8 @@ def test_timing_period_samples_runs_and_changes_no_result(solver):
 
 
 def test_shard_combiner_exact_pipeline_one_rank_rccl():
-    """The staged pipeline bench.py --gpus N runs (all-gather -> strict re-score of near-tied shards -> all-gather ->
-    combine), rehearsed over RCCL with a one-rank group on this GPU: every solve's combined winner is its own winner,
+    """The pipeline bench.py --gpus N runs (winner records with controls -> one all-gather -> exact combine),
+    rehearsed over RCCL with a one-rank group on this GPU: every solve's combined winner is its own winner,
     through full batches, a partial one and slot wrap-around; a lone shard never ties."""
     import os
     import torch
@@ -288,7 +288,7 @@ def test_shard_combiner_exact_pipeline_one_rank_rccl():
         with torch.cuda.stream(stream):
             solver = M.Solver(0, stream=stream.cuda_stream)          # collectives and kernels ordered on one stream
             p = W.config2_problem(depth=5)
-            comb = ShardCombiner(solver, 1, ordinal_stride=0, batch=3, slots=3, always=True, exact=True)
+            comb = ShardCombiner(solver, 1, ordinal_stride=0, batch=3, slots=3, always=True, exact=True, depth=5)
             assert comb.exact and comb.collective
             seen = []
             for k in range(11):                                      # 3 full batches + a partial one: slots wrap

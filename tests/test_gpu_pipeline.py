@@ -106,3 +106,50 @@ def test_deferred_finish_on_a_fleet_and_with_timing():
         solver.set_timing(1)
     finally:
         solver.close()
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_winner_record_sink_carries_the_winners_controls(pipeline):
+    """mpc_hip_set_winner_record_sink / mpc_hip_copy_winner_records: (score bits, ordinal) as the plain sink writes
+    them, then the winner's clamped controls per level -- the ones in the fetched trajectory, bit for bit -- for every
+    size of candidate set (one lane, snapshot finish, two-kernel finish), explicit and seeded, on a fleet whose
+    problems are shallower than the record, immediate and deferred finish."""
+    torch = _torch()
+    solver = M.Solver(0)
+    try:
+        depth, rec_depth = 9, 12
+        Wd = M.winner_record_words(rec_depth)
+        probs, seeds = W.fleet_problems(5, depth=depth)
+        solver.upload(probs, seeds)
+        solver.set_pipeline(pipeline)
+        sizes = [1, 60, 777, 4096, 70000]
+        sink = torch.full((len(sizes), 5, Wd), -7, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        fetched = []
+        for k, n in enumerate(sizes):
+            solver.set_winner_record_sink(sink[k], rec_depth)
+            solver.run_seeded(100 * k, n, M.PREC_FAST)
+            packed = torch.full((5, Wd), -9, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            solver.copy_winner_records(packed, rec_depth)            # (flushes a deferred finish)
+            fetched.append((solver.fetch(), packed))
+        solver.set_winner_record_sink(None, rec_depth)
+        solver.synchronize()
+        torch.cuda.synchronize()
+        for k, (res, packed) in enumerate(fetched):
+            for q in range(5):
+                rec = sink[k, q].cpu().numpy()
+                assert rec[0] == np.float64(res[q].best_last).view(np.int64) and rec[1] == res[q].best_ordinal
+                tr = traj_array(res[q])                              # [depth + 1, 7]: x y heading speed time rudder throttle? see helpers
+                ctl = rec[2:2 + 2 * depth].view(np.float64).reshape(depth, 2)
+                want = np.array([[res[q].trajectory[l + 1].rudder, res[q].trajectory[l + 1].throttle] for l in range(depth)])
+                assert np.array_equal(ctl.view(np.int64), want.view(np.int64)), (k, q)
+                assert (rec[2 + 2 * depth:] == -7).all()             # nothing beyond the problem's depth is touched
+                assert np.array_equal(packed[q].cpu().numpy()[:2 + 2 * depth], rec[:2 + 2 * depth])
+        with pytest.raises(M.MpcError):                              # a record shallower than a resident problem
+            solver.set_winner_record_sink(sink[0], depth - 1)
+            solver.run_seeded(0, 64, M.PREC_FAST)
+        solver.set_winner_record_sink(None, rec_depth)
+        solver.set_pipeline(False)
+    finally:
+        solver.close()
