@@ -67,13 +67,14 @@ def cpu_baseline(problem, seed, want_ordinal):
     }
 
 
-def measured_valu(k1_seconds):
+def measured_valu(k1_seconds, spl=1):
     """SURVEY.md 8d's second figure: rocprof-counted VALU instructions x 64 lanes / (kernel time x peak lane-issue
     rate 256 CU x 4 SIMD x 16 lanes x 2.4 GHz).  The instruction count comes from the committed PMC pass of this
     command (counters cannot be read inside the timed process), the time is this run's."""
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-        insts = float(prof["sq_insts_valu"])
+        scale = spl / float(prof.get("solves_per_launch", 1))       # the profile's launch may hold another number of solves
+        insts = float(prof["sq_insts_valu"]) * scale
     except Exception:
         return None
     out = {"sq_insts_valu_per_launch": insts, "lane_issue_frac": insts * 64 / (k1_seconds * 256 * 4 * 16 * 2.4e9),
@@ -81,7 +82,7 @@ def measured_valu(k1_seconds):
     try:        # hardware-counted FP64 operations (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 lanes, FMA = 2 FLOP)
         for ln in open(os.path.join(ROOT, "profiles", "r02_fp64_flop_counters.txt")):
             if ln.startswith("config2 |"):
-                flop = float(ln.split("|")[5])
+                flop = float(ln.split("|")[5]) * spl            # (that table is per solve: its probe runs one solve per launch)
                 out["counted_fp64_flop_per_launch"] = flop
                 out["counted_fp64_tflops"] = flop / k1_seconds / 1e12
                 out["counted_fp64_frac_of_peak"] = flop / k1_seconds / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
@@ -90,12 +91,13 @@ def measured_valu(k1_seconds):
     return out
 
 
-def measured_traffic():
+def measured_traffic(spl=1):
     """HBM bytes per rollout-kernel launch from the committed PMC profile of this same command (rocprofv3 --pmc
     cannot run inside the timed process); None if no profile has been committed."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
-        return json.load(open(path))["hbm_bytes_per_launch"]
+        prof = json.load(open(path))
+        return int(prof["hbm_bytes_per_launch"] * spl / float(prof.get("solves_per_launch", 1)))
     except Exception:
         return None
 
@@ -120,6 +122,9 @@ def main():
                          "covered, at most 64 regions")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="two kernels per solve (rollouts, finish) instead of the deferred finish (mpc_hip_set_pipeline)")
+    ap.add_argument("--pipeline-level", type=int, choices=[0, 1, 2], default=2,
+                    help="mpc_hip_set_pipeline: 1 = every solve's finish rides in the next solve's rollout launch; 2 = also two "
+                         "solves per launch (a 65,536-candidate set is one wave per SIMD: the second wave comes from the next solve)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -226,7 +231,10 @@ def main():
 
         # a stream of solves: each run's finish rides in the next run's rollout launch (one dispatch per solve); the
         # results are bit for bit those of the two-kernel form (tests/test_gpu_pipeline.py)
-        solver.set_pipeline(not args.no_pipeline)
+        level = 0 if args.no_pipeline else args.pipeline_level
+        solver.set_pipeline(level)
+        # solves per rollout launch: level 2 pairs the one-wave-per-SIMD solves of config 2 (fast precision) and nothing else
+        spl = 2 if (level == 2 and args.workload == "config2" and prec == M.PREC_FAST) else 1
         solver.set_timing(0)
         t_ramp = time.perf_counter()
         while time.perf_counter() - t_ramp < args.ramp_seconds and args.workload == "config2":
@@ -296,8 +304,9 @@ def main():
     steps_per_solve = n_problems * count * depth * nsub
     value = world * steps_per_solve * args.steps / elapsed
     k1_ms = k1_ms_sum / max(runs, 1)
-    flop = n_problems * count * depth * (FLOP_PER_STEP * nsub + FLOP_PER_SCORE)
-    hbm_bytes = n_problems * count * ((2 * 4 * depth if args.workload == "config2" else 0) + 3 * 8)
+    # per LAUNCH of the dominant kernel: spl solves
+    flop = spl * n_problems * count * depth * (FLOP_PER_STEP * nsub + FLOP_PER_SCORE)
+    hbm_bytes = spl * n_problems * count * ((2 * 4 * depth if args.workload == "config2" else 0) + 3 * 8)
     if rank == 0:
         line = {
             "metric": "candidate_rollout_steps_per_sec",
@@ -314,7 +323,7 @@ def main():
             "config": {"workload": what, "candidates_per_gpu": n_problems * count, "problems_per_gpu": n_problems,
                        "depth": depth, "substeps_per_level": nsub,
                        "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
-                       "selection": "last_step", "deferred_finish": not args.no_pipeline,
+                       "selection": "last_step", "deferred_finish": level >= 1, "pipeline_level": level, "solves_per_launch": spl,
                        "parallelism": ("candidate shards; per %d solves ONE async RCCL all-gather of the winner records (score, ordinal, controls), then "
                                        "mpc_hip_combine_shards_exact: strict re-score of cross-shard near-ties from the gathered controls, "
                                        "the reference's first strict minimum across GPUs" % args.combine_batch if combine else
@@ -322,8 +331,9 @@ def main():
             "clock_ramp_s": args.ramp_seconds if args.workload == "config2" else 0.0,
             "p50_solve_latency_ms": p50,
             "rollout_kernel_ms": k1_ms,
-            "kernel_timing": "HIP events attached to the K1/K2 dispatches of %d of the %d timed solves (every %d-th)" % (
-                runs, args.steps * len(regions), max(1, min(args.timing_period, args.steps))),
+            "kernel_timing": "HIP events attached to %d rollout dispatches of the %d timed solves (every %d-th solve's; a dispatch "
+                             "holds %d solve%s)" % (runs, args.steps * len(regions), max(1, min(args.timing_period, args.steps)), spl,
+                                                    "s" if spl > 1 else ""),
             "solve_gpu_ms": total_ms_sum / max(runs, 1),
             "chosen": {"ordinal": int(res.best_ordinal) + offset, "rudder": res.first_rudder,
                        "throttle": res.first_throttle, "last_score": res.best_last,
@@ -333,12 +343,12 @@ def main():
                 "bound": "valu",
                 "bound_note": "FP64 vector ALU (SURVEY.md 8d): neither mfma nor hbm -- sequential per-candidate ODE "
                               "integration, no dense contraction; HBM figures under 'hbm'",
-                "kernel": "rollout_kernel", "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "kernel": "rollout_pair_kernel" if spl == 2 else "rollout_kernel", "solves_per_launch": spl, "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flop / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                "traffic": measured_traffic() if args.workload == "config2" and prec == M.PREC_FAST else None,
+                "traffic": measured_traffic(spl) if args.workload == "config2" and prec == M.PREC_FAST else None,
                 "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-                "measured_valu": measured_valu(k1_ms * 1e-3) if args.workload == "config2" and prec == M.PREC_FAST else None,
-                "algorithmic_flop_per_launch": flop, "kernel_steps_per_sec": steps_per_solve / (k1_ms * 1e-3),
+                "measured_valu": measured_valu(k1_ms * 1e-3, spl) if args.workload == "config2" and prec == M.PREC_FAST else None,
+                "algorithmic_flop_per_launch": flop, "kernel_steps_per_sec": spl * steps_per_solve / (k1_ms * 1e-3),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,
                         "achieved_GBps": hbm_bytes / (k1_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS},
             },

@@ -316,7 +316,15 @@ int         mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_ga
  * the collective that reads it).  The winner sink in force when a run was ENQUEUED is the one its finish writes.
  * Results are bit for bit those of the two-kernel form.  The one-call forms (mpc_hip_eval_*) fetch and therefore
  * never defer; runs that have no fused variant (strict precision, non-uniform schedules, >= 2^20 candidates) finish
- * the pending solve with a launch of its own first.  Off by default.  No counterpart in the reference. */
+ * the pending solve with a launch of its own first.  Off by default.  No counterpart in the reference.
+ * Level 2 (on == 2) adds TWO RUNS PER LAUNCH: a 65,536-candidate set is one wave per SIMD, and a lone wave issues an
+ * instruction every ~6.2 cycles where the SIMD could take one every 4 -- the second wave can only come from another
+ * solve.  A run that can pair up (MPC_PREC_FAST, uniform substeps, fewer than 2^20 candidates) is only PREPARED by its
+ * call and goes to the GPU together with the next such run, in one dispatch that also carries the finish workgroups of
+ * the two runs before (+17 % on a stream of 65,536-candidate solves).  What changes for the caller: the device arrays
+ * a run reads and writes (controls, cost outputs, winner sink) are used from the stream position of the NEXT run -- or
+ * of the call that asks for results, which sends a run without a partner alone -- so they must stay as they are
+ * until then; everything else is as at level 1, results bit for bit. */
 int         mpc_hip_set_pipeline(mpc_hip_handle *h, int on);
 int         mpc_hip_flush(mpc_hip_handle *h);
 /* Which runs carry HIP events: every `period`-th run of the handle (1 = all, the default; 0 = none).  The events

@@ -147,7 +147,7 @@ extern "C" void mpc_hip_destroy(mpc_hip_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_probs); (void)hipHostFree(h->h_probs);
-    (void)hipFree(h->d_results); (void)hipHostFree(h->h_results);
+    (void)hipFree(h->d_results); (void)hipHostFree(h->h_results); (void)hipFree(h->d_results_alt); (void)hipFree(h->d_winners_alt);
     (void)hipFree(h->d_winners); (void)hipFree(h->d_list_count); (void)hipFree(h->d_pcnt);
     (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord);
     for (WorkMem &w : h->wm) { (void)hipFree(w.d_keys); (void)hipFree(w.d_snap); (void)hipFree(w.d_pkey); (void)hipFree(w.d_pord); (void)hipFree(w.d_pcnt); }
@@ -174,9 +174,9 @@ int mpc_ensure_problem_capacity(mpc_hip_handle *h, uint32_t n)
     HIP_TRY(hipStreamSynchronize(h->stream));
     (void)hipFree(h->d_probs); (void)hipHostFree(h->h_probs); (void)hipFree(h->d_results);
     (void)hipHostFree(h->h_results); (void)hipFree(h->d_winners);
-    (void)hipFree(h->d_list_count);
+    (void)hipFree(h->d_list_count); (void)hipFree(h->d_results_alt); (void)hipFree(h->d_winners_alt);
     h->d_probs = nullptr; h->h_probs = nullptr; h->d_results = nullptr; h->h_results = nullptr;
-    h->d_winners = nullptr; h->d_list_count = nullptr;
+    h->d_winners = nullptr; h->d_list_count = nullptr; h->d_results_alt = nullptr; h->d_winners_alt = nullptr;
     h->cap_probs = 0;
     HIP_TRY(hipMalloc(&h->d_probs, sizeof(DevProblem) * n));
     HIP_TRY(hipHostMalloc(&h->h_probs, sizeof(DevProblem) * n));
@@ -184,6 +184,8 @@ int mpc_ensure_problem_capacity(mpc_hip_handle *h, uint32_t n)
     HIP_TRY(hipHostMalloc(&h->h_results, sizeof(DevResult) * n));
     HIP_TRY(hipMalloc(&h->d_winners, sizeof(uint64_t) * (2 * (size_t)n + 4)));   /* the tree search uses 4 words */
     HIP_TRY(hipMalloc(&h->d_list_count, sizeof(uint32_t) * n));
+    HIP_TRY(hipMalloc(&h->d_results_alt, sizeof(DevResult) * n));
+    HIP_TRY(hipMalloc(&h->d_winners_alt, sizeof(uint64_t) * 2 * (size_t)n));
     h->cap_probs = n;
     return MPC_OK;
 }
@@ -353,8 +355,36 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
  * next run's K1 launch carries it as one extra workgroup per problem (rollout_kernel<.., FUSE>), and any call that
  * needs the results (fetch, winners, upload, synchronize, ...) launches it on its own first.  Working memory that K1
  * writes and K2 reads is double-buffered (h->wm[2]) so that K1 of solve n+1 never overwrites what K2 of solve n reads. */
+static int launch_pair(mpc_hip_handle *h, const StashedRun *second);
+
+static int finish_standalone(mpc_hip_handle *h, const StashedRun &r)
+{
+    const dim3 grid(r.n_probs), blk(256);
+    if (r.seeded) hipLaunchKernelGGL((finish_kernel<true>), grid, blk, 0, h->stream, r.fin);
+    else hipLaunchKernelGGL((finish_kernel<false>), grid, blk, 0, h->stream, r.fin);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+/* level 2's part: the run waiting for a partner and the finishes of the last launch's runs */
+static int flush_pairs(mpc_hip_handle *h)
+{
+    if (h->stashed) { if (int s = launch_pair(h, nullptr)) return s; }      /* a run without a partner goes alone */
+    if (h->n_pend2 == 2) {                                                  /* the two runs of one launch: one launch for both */
+        const dim3 grid(h->pend2[0].n_probs, 2), blk(256);                  /* (they write different result buffers) */
+        if (h->pend2[0].seeded) hipLaunchKernelGGL((finish2_kernel<true>), grid, blk, 0, h->stream, h->pend2[0].fin, h->pend2[1].fin);
+        else hipLaunchKernelGGL((finish2_kernel<false>), grid, blk, 0, h->stream, h->pend2[0].fin, h->pend2[1].fin);
+        HIP_TRY(hipGetLastError());
+    } else if (h->n_pend2 == 1) {
+        if (int s = finish_standalone(h, h->pend2[0])) return s;
+    }
+    h->n_pend2 = 0;
+    return MPC_OK;
+}
+
 static int flush_pending(mpc_hip_handle *h)
 {
+    if (int s = flush_pairs(h)) return s;
     if (!h->pending) return MPC_OK;
     hipEvent_t *ev = &h->ev[4 * h->pend_slot];
     hipEvent_t k2a = h->pend_timed ? ev[2] : nullptr, k2b = h->pend_timed ? ev[3] : nullptr;
@@ -375,6 +405,51 @@ static int ensure_buffer(mpc_hip_handle *h, void **buf, size_t *cap, size_t need
     (void)hipFree(*buf); *buf = nullptr; *cap = 0;
     HIP_TRY(hipMalloc(buf, need_bytes));
     *cap = need_bytes;
+    return MPC_OK;
+}
+
+/* ---- two runs per launch (mpc_hip_set_pipeline level 2) ---------------------------------------------------------
+ * A 65,536-candidate set is one wave per SIMD; the second wave a SIMD needs to issue a VALU instruction every 4 cycles
+ * instead of every ~6.2 can only come from another solve.  At level 2 a run that can pair up (fast, uniform substeps,
+ * one-wave workgroups) is only PREPARED by its call and launched together with the next such run, in one dispatch that
+ * also carries the finish workgroups of the launch before (rollout_pair_kernel); a run without a partner goes alone
+ * when anything asks for results (flush_pending).  Working memory rotates over four sets: the two runs being launched
+ * and the two whose finishes ride along. */
+static int launch_pair(mpc_hip_handle *h, const StashedRun *second)
+{
+    const StashedRun first = h->stash;
+    h->stashed = false;
+    /* finishes that cannot ride along (another candidate source or batch size) go first, on their own */
+    if (h->n_pend2 && (h->pend2[0].seeded != first.seeded || h->pend2[0].n_probs != first.n_probs)) {
+        for (int i = 0; i < h->n_pend2; i++)
+            if (int s = finish_standalone(h, h->pend2[i])) return s;
+        h->n_pend2 = 0;
+    }
+    PairArgs A{};
+    A.run[0] = first.run;
+    if (second) A.run[1] = second->run;                  /* else nblk == 0: no workgroups */
+    for (int i = 0; i < h->n_pend2; i++) A.prev[i] = h->pend2[i].fin;
+    const uint32_t n_prev = (uint32_t)h->n_pend2;
+    const dim3 grid(A.run[0].nblk + A.run[1].nblk + n_prev, first.n_probs), blk(64);
+    const size_t lds = second ? std::max(first.lds, second->lds) : first.lds;
+    const StashedRun *t = first.timed ? &first : (second && second->timed ? second : nullptr);   /* one pair of events per dispatch */
+    hipEvent_t k1a = t ? h->ev[4 * t->slot] : nullptr, k1b = t ? h->ev[4 * t->slot + 1] : nullptr;
+    h->timed[first.slot] = t == &first;
+    if (second) h->timed[second->slot] = t == second;
+    if (t) h->total_from_k1[t->slot] = 1;                /* the finishes have no dispatch of their own */
+#define LAUNCH_PAIR(SEEDED, PREGEN) \
+    hipExtLaunchKernelGGL((rollout_pair_kernel<SEEDED, PREGEN>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A)
+    if (first.seeded) { if (first.pregen) LAUNCH_PAIR(true, true); else LAUNCH_PAIR(true, false); }
+    else LAUNCH_PAIR(false, false);
+#undef LAUNCH_PAIR
+    HIP_TRY(hipGetLastError());
+    h->n_pend2 = 0;
+    h->pend2[h->n_pend2] = first;
+    if (second) {                                        /* two finishes in one launch: only the newer writes the handle's results */
+        h->pend2[0].fin.results = h->d_results_alt; h->pend2[0].fin.winners = h->d_winners_alt;
+        h->pend2[1] = *second;
+        h->n_pend2 = 2;
+    } else h->n_pend2 = 1;
     return MPC_OK;
 }
 
@@ -419,10 +494,19 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
                 mpc_set_err("the winner record sink is too shallow for a resident problem (mpc_hip_set_winner_record_sink depth)");
                 return MPC_ERR_INVALID;
             }
-    /* which half of the working memory this run writes: the other one may still be read by a pending finish */
+    const int fast = precision == MPC_PREC_FAST;
+    /* all substeps of a level equally long (configs 2-5): the kernels keep the schedule row in registers */
+    bool uniform = true;
+    for (uint32_t p = 0; p < h->n_probs && uniform; p++)
+        for (int s = 1; s < h->nsub[p]; s++)
+            if (h->h_probs[p].sub[s * SUB_STRIDE] != h->h_probs[p].sub[0]) { uniform = false; break; }
+    /* level 2 pairs up what the pair kernel has a variant for; any other run is treated as at level 1 */
     const bool pipelined = h->pipeline && !use_static;
-    if (h->pending && !pipelined) { if (int s = flush_pending(h)) return s; }
-    const int half = pipelined ? (h->pending ? 1 - h->pend_half : 0) : 0;
+    const bool pairable = pipelined && h->pipeline == 2 && fast && uniform && block == 64;
+    if (!pipelined || (pairable && h->pending)) { if (int s = flush_pending(h)) return s; }
+    else if (!pairable) { if (int s = flush_pairs(h)) return s; }
+    /* which set of the working memory this run writes: the others may still be read by pending finishes */
+    const int half = pairable ? (int)(h->wm_rr++ & 3u) : pipelined ? (h->pending ? 1 - h->pend_half : 0) : 0;
     WorkMem &wm = h->wm[half];
     double *d_keys; uint64_t *d_pkey, *d_pord; uint32_t *d_pcnt;
     if (use_static) {
@@ -462,18 +546,12 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
         if (int s = ensure_buffer(h, (void **)&wm.d_snap, &wm.cap_snap, sizeof(double) * snap_need)) return s;
         d_snap = wm.d_snap;
     }
-    const int fast = precision == MPC_PREC_FAST;
     const double rel = fast ? MPC_REFINE_REL : 0.0;
-    /* all substeps of a level equally long (configs 2-5): the kernels keep the schedule row in registers */
-    bool uniform = true;
-    for (uint32_t p = 0; p < h->n_probs && uniform; p++)
-        for (int s = 1; s < h->nsub[p]; s++)
-            if (h->h_probs[p].sub[s * SUB_STRIDE] != h->h_probs[p].sub[0]) { uniform = false; break; }
     const uint32_t slot = (uint32_t)(h->runs % TIMING_RING);
     hipEvent_t *ev = &h->ev[4 * slot];
     /* the pending finish rides along when this launch has a variant for it: fast uniform rollouts in one-wave
      * workgroups (every throughput stream of small sets: config 2), the same kind of candidate source, the same batch */
-    const bool fuse = pipelined && h->pending && fast && uniform && block == 64 && h->pend_seeded == seeded &&
+    const bool fuse = pipelined && !pairable && h->pending && fast && uniform && block == 64 && h->pend_seeded == seeded &&
                       h->pend_n_probs == h->n_probs;
     if (h->pending && !fuse) { if (int s = flush_pending(h)) return s; }
     const dim3 grid(nblk + (fuse ? 1u : 0u), h->n_probs), blk(block);
@@ -481,9 +559,9 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
      * a fused finish keeps its near-tie list (+ 16 words) in the same place */
     /* small seeded sets (fast, one-wave workgroups, depth <= 32): every level's controls are generated into LDS by the
      * prologue (PREGEN, mpc_kernels.h): 2 * depth * 64 doubles */
-    const bool pregen = seeded && fast && block == 64 && snap_depth <= 32;
+    const bool pregen = seeded && fast && block == 64 && snap_depth <= 32 && !pairable;   /* (two waves per SIMD: 2 x 4 x 28 KB would not fit a CU's LDS) */
     size_t ctl_bytes = seeded ? (pregen ? sizeof(double) * 2 * (size_t)snap_depth * block : 0) : sizeof(float) * 2 * (size_t)snap_depth * block;
-    if (fuse) ctl_bytes = std::max(ctl_bytes, sizeof(uint64_t) * (LIST_CAP + FINISH_LDS_WORDS));
+    if (fuse || pairable) ctl_bytes = std::max(ctl_bytes, sizeof(uint64_t) * (LIST_CAP + FINISH_LDS_WORDS));
     const size_t lds = K1_LDS_BASE + ctl_bytes;
     if (lds > K1_LDS_LIMIT) { mpc_set_err("rollout kernel: staged controls do not fit the workgroup's LDS"); return MPC_ERR_TOO_LARGE; }
     /* timed runs carry their events ON the dispatches (the kernels' own begin/end, as a profiler reads them):
@@ -492,6 +570,28 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     h->timed[slot] = timed;
     h->total_from_k1[slot] = 0;
     if (fuse) h->total_from_k1[h->pend_slot] = 1;          /* that run's finish has no dispatch of its own: hidden in this K1 */
+    const FinishArgs fin{h->d_probs, d_rud, d_thr, first, count, selection, fast, (int)uniform, rel, nblk, cpb,
+                         d_pkey, d_pord, d_pcnt, d_keys, d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->winner_sink_words, 0u,
+                         h->d_results};
+    if (pairable) {
+        const StashedRun rec{RunArgs{d_rud, d_thr, first, count, selection, snap_depth, rel, d_cost_last, d_cost_cum, d_keys, d_snap,
+                                     d_pkey, d_pord, d_pcnt, nblk, 0u},
+                             fin, seeded, pregen, timed, lds, h->n_probs, slot};
+        h->timed[slot] = false;                                         /* set by the launch that carries the events */
+        int s = MPC_OK;
+        if (h->stashed && h->stash.seeded == seeded && h->stash.pregen == pregen && h->stash.n_probs == h->n_probs)
+            s = launch_pair(h, &rec);
+        else {
+            if (h->stashed) s = launch_pair(h, nullptr);
+            h->stash = rec; h->stashed = true;
+        }
+        if (s) return s;
+        h->runs++;
+        h->last_count = count; h->last_first = first; h->last_precision = precision; h->last_selection = selection;
+        h->last_seeded = seeded; h->ran = true;
+        h->last_rud = d_rud; h->last_thr = d_thr;
+        return MPC_OK;
+    }
     hipEvent_t k1a = timed ? ev[0] : nullptr, k1b = timed ? ev[1] : nullptr;
     const FinishArgs prev = fuse ? h->pend : FinishArgs{};
 #define LAUNCH_K1(PREC, SEEDED)                                                                               \
@@ -514,9 +614,7 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
 #undef LAUNCH_K1P
     HIP_TRY(hipGetLastError());
     /* this run's finish: pending (pipeline) or launched right away */
-    h->pend = FinishArgs{h->d_probs, d_rud, d_thr, first, count, selection, fast, (int)uniform, rel, nblk, cpb,
-                         d_pkey, d_pord, d_pcnt, d_keys, d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->winner_sink_words, 0u,
-                         h->d_results};
+    h->pend = fin;
     h->pending = true; h->pend_seeded = seeded; h->pend_n_probs = h->n_probs; h->pend_half = half;
     h->pend_slot = slot; h->pend_timed = timed;
     if (!pipelined) { if (int s = flush_pending(h)) return s; }
@@ -552,8 +650,9 @@ extern "C" int mpc_hip_set_pipeline(mpc_hip_handle *h, int on)
 {
     if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
     if (int s = mpc_use_device(h)) return s;
-    if (!on) { if (int s = flush_pending(h)) return s; }
-    h->pipeline = on != 0;
+    if (on < 0 || on > 2) { mpc_set_err("set_pipeline: level out of range [0, 2]"); return MPC_ERR_INVALID; }
+    if (on != h->pipeline) { if (int s = flush_pending(h)) return s; }
+    h->pipeline = on;
     return MPC_OK;
 }
 
@@ -636,7 +735,7 @@ static int fetch_internal(mpc_hip_handle *h, mpc_result *h_results, uint32_t n_p
     hipEvent_t *ev = &h->ev[4 * ((h->runs - 1) % TIMING_RING)];
     if (h->timed[(h->runs - 1) % TIMING_RING]) {
         (void)hipEventElapsedTime(&k1, ev[0], ev[1]);
-        (void)hipEventElapsedTime(&total, ev[0], ev[3]);
+        (void)hipEventElapsedTime(&total, ev[0], h->total_from_k1[(h->runs - 1) % TIMING_RING] ? ev[1] : ev[3]);
     }
     bool overflow = false;
     for (uint32_t p = 0; p < n_problems; p++) overflow |= h->h_results[p].overflow != 0;

@@ -87,6 +87,25 @@ struct FinishArgs {
     uint32_t sink_words, pad;
     DevResult *results;
 };
+/* what K1 needs of one run: rollout_pair_kernel (mpc_hip_set_pipeline level 2) takes two of these */
+struct RunArgs {
+    const float *rud, *thr;
+    uint64_t first, count;
+    int selection, snap_depth;
+    double rel;
+    double *cost_last, *cost_cum, *keys, *snap;
+    uint64_t *pkey, *pord;
+    uint32_t *pcnt;
+    uint32_t nblk, pad;
+};
+/* a run that is prepared but not launched yet (level 2: it waits for a partner) */
+struct StashedRun {
+    RunArgs run;
+    FinishArgs fin;
+    bool seeded, pregen, timed;
+    size_t lds;
+    uint32_t n_probs, slot;
+};
 /* what K1 writes and K2 reads, twice (mpc_hip_set_pipeline): half 0's workgroup triples are h->d_pkey/d_pord/d_pcnt,
  * shared with the tree search */
 struct WorkMem {
@@ -119,9 +138,18 @@ struct mpc_hip_handle {
     uint64_t *d_pkey = nullptr, *d_pord = nullptr;              /* K1 workgroup triples */
     uint32_t *d_pcnt = nullptr;
     size_t cap_partials = 0;
-    WorkMem wm[2];                                              /* keys, snapshots (and half 1's triples) */
+    WorkMem wm[4];                                              /* keys, snapshots (and the triples of all but wm[0]); level 1 uses two, level 2 four */
     /* deferred finish (mpc_hip.hip) */
-    bool pipeline = false, pending = false, pend_seeded = false, pend_timed = false;
+    int pipeline = 0;                                           /* 0 off, 1 deferred finish, 2 two runs per launch + deferred finish */
+    bool pending = false, pend_seeded = false, pend_timed = false;
+    /* level 2: a run waiting for its partner, and the (<= 2) runs of the last launch whose finishes are pending */
+    bool stashed = false;
+    StashedRun stash;
+    int n_pend2 = 0;
+    StashedRun pend2[2];
+    uint32_t wm_rr = 0;
+    DevResult *d_results_alt = nullptr;                         /* where the OLDER of two finishes in one launch writes */
+    uint64_t *d_winners_alt = nullptr;
     FinishArgs pend{};
     uint32_t pend_n_probs = 0, pend_slot = 0;
     int pend_half = 0;

@@ -482,6 +482,16 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs A)
     finish_body<SEEDED, 4>(A, blockIdx.x, lds, s_list, small);
 }
 
+/* the finishes of the two runs of one launch (mpc_hip_set_pipeline level 2), when nothing follows to carry them */
+template <bool SEEDED>
+__global__ __launch_bounds__(256) void finish2_kernel(const FinishArgs a, const FinishArgs b)
+{
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ uint64_t s_list[LIST_CAP];
+    __shared__ uint64_t small[FINISH_LDS_WORDS];
+    finish_body<SEEDED, 4>(blockIdx.y ? b : a, blockIdx.x, lds, s_list, small);
+}
+
 /* ------------------------------------------------------------------------------------------------------ */
 /* K1: rollout + cost + block argmin                                                                       */
 /* ------------------------------------------------------------------------------------------------------ */
@@ -493,30 +503,23 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs A)
  * finishes solve n -- which serialises the same chain behind the rollout: slower than two kernels.)  Its LDS comes out
  * of the dynamic allocation: the problem staging area it shares by layout, the near-tie list sits where a rollout
  * workgroup keeps its controls (the host sizes the allocation for both). */
-template <int PREC, bool SEEDED, bool UNIFORM, bool FUSE = false, bool PREGEN = false>
-__global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restrict__ probs,
-                                                      const float *__restrict__ rud, const float *__restrict__ thr,
-                                                      uint64_t first, uint64_t count, int selection, double refine_rel,
-                                                      double *__restrict__ cost_last, double *__restrict__ cost_cum,
-                                                      double *__restrict__ keys, double *__restrict__ snap_base,
-                                                      int snap_depth, uint64_t *__restrict__ pkey,
-                                                      uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt,
-                                                      const FinishArgs prev)
+/* one rollout workgroup: workgroup `bx` of the `n_rollout_blocks` of its run (problem blockIdx.y) */
+template <int PREC, bool SEEDED, bool UNIFORM, bool PREGEN>
+__device__ __forceinline__ void rollout_body(const DevProblem *__restrict__ probs,
+                                             const float *__restrict__ rud, const float *__restrict__ thr,
+                                             uint64_t first, uint64_t count, int selection, double refine_rel,
+                                             double *__restrict__ cost_last, double *__restrict__ cost_cum,
+                                             double *__restrict__ keys, double *__restrict__ snap_base,
+                                             int snap_depth, uint64_t *__restrict__ pkey,
+                                             uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt,
+                                             const uint32_t bx, const uint32_t n_rollout_blocks, double *lds)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cpL = lds;
     double *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     uint64_t *red = (uint64_t *)(subL + MPC_MAX_SUBSTEPS * SUB_STRIDE);       /* 8 words argmin + 2 words (+ 2 pad) */
     float *ctlL = (float *)(red + 12);                                         /* [depth][2][blockDim] (explicit sets) */
-    const uint32_t n_rollout_blocks = FUSE ? gridDim.x - 1 : gridDim.x;
-    if (FUSE && blockIdx.x == n_rollout_blocks) {                              /* uniform per workgroup */
-        /* FINISH_LDS_WORDS (16) > the 12 words at `red`: the small state goes behind the list */
-        uint64_t *s_list = (uint64_t *)ctlL;
-        finish_body<SEEDED, 16>(prev, blockIdx.y, lds, s_list, s_list + LIST_CAP);
-        return;
-    }
     const DevProblem &P = probs[blockIdx.y];
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = (uint64_t)bx * blockDim.x + threadIdx.x;
     /* prologue: every global load of the workgroup is issued before the first wait (problem record, then controls;
      * explicit sets hold one problem, whose depth is snap_depth) */
     StagedProblem staged;
@@ -582,9 +585,56 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
     if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint64_t b = (uint64_t)blockIdx.y * n_rollout_blocks + blockIdx.x;
+        const uint64_t b = (uint64_t)blockIdx.y * n_rollout_blocks + bx;
         pkey[b] = k; pord[b] = o; pcnt[b] = *cnt;
     }
+}
+
+template <int PREC, bool SEEDED, bool UNIFORM, bool FUSE = false, bool PREGEN = false>
+__global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restrict__ probs,
+                                                      const float *__restrict__ rud, const float *__restrict__ thr,
+                                                      uint64_t first, uint64_t count, int selection, double refine_rel,
+                                                      double *__restrict__ cost_last, double *__restrict__ cost_cum,
+                                                      double *__restrict__ keys, double *__restrict__ snap_base,
+                                                      int snap_depth, uint64_t *__restrict__ pkey,
+                                                      uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt,
+                                                      const FinishArgs prev)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const uint32_t n_rollout_blocks = FUSE ? gridDim.x - 1 : gridDim.x;
+    if (FUSE && blockIdx.x == n_rollout_blocks) {                              /* uniform per workgroup */
+        /* the near-tie list sits where a rollout workgroup keeps its controls; FINISH_LDS_WORDS (16) > the 12 argmin
+         * words before them: the small state goes behind the list */
+        uint64_t *s_list = (uint64_t *)(lds + MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + 12;
+        finish_body<SEEDED, 16>(prev, blockIdx.y, lds, s_list, s_list + LIST_CAP);
+        return;
+    }
+    rollout_body<PREC, SEEDED, UNIFORM, PREGEN>(probs, rud, thr, first, count, selection, refine_rel, cost_last, cost_cum, keys,
+                                                snap_base, snap_depth, pkey, pord, pcnt, blockIdx.x, n_rollout_blocks, lds);
+}
+
+/* Two runs in ONE launch (mpc_hip_set_pipeline level 2).  A 65,536-candidate set is one wave per SIMD, and a lone wave
+ * issues a VALU instruction every ~6.2 cycles instead of every 4: the second wave per SIMD can only come from another
+ * solve.  The grid is run a's workgroups, then run b's (b.nblk == 0: none), then one finish workgroup per PENDING run
+ * (n_prev <= 2: the previous launch's runs) -- fast uniform rollouts in one-wave workgroups only.  The run's arguments
+ * are picked by a workgroup-uniform index into the kernel argument block (scalar loads, one copy of the body). */
+struct PairArgs { RunArgs run[2]; FinishArgs prev[2]; };
+
+template <bool SEEDED, bool PREGEN>
+__global__ __launch_bounds__(256) void rollout_pair_kernel(const DevProblem *__restrict__ probs, const PairArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const uint32_t na = A.run[0].nblk, nr = na + A.run[1].nblk;
+    if (blockIdx.x >= nr) {
+        uint64_t *s_list = (uint64_t *)(lds + MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + 12;
+        finish_body<SEEDED, 16>(A.prev[blockIdx.x - nr], blockIdx.y, lds, s_list, s_list + LIST_CAP);
+        return;
+    }
+    const uint32_t w = blockIdx.x >= na ? 1u : 0u;
+    const RunArgs &R = A.run[w];
+    rollout_body<MPC_PREC_FAST, SEEDED, true, PREGEN>(probs, R.rud, R.thr, R.first, R.count, R.selection, R.rel, R.cost_last, R.cost_cum,
+                                                      R.keys, R.snap, R.snap_depth, R.pkey, R.pord, R.pcnt, blockIdx.x - (w ? na : 0u),
+                                                      R.nblk, lds);
 }
 
 /* multi-GPU: lexicographic (score bits, global ordinal) minimum over the gathered per-shard winners */

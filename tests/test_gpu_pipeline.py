@@ -67,7 +67,10 @@ def _stream_of_solves(solver, pipeline, plan):
 
 @pytest.mark.parametrize("plan", [
     ["seeded"] * 6,
+    ["seeded"] * 7,
     ["explicit"] * 5,
+    ["explicit"] * 8,
+    ["seeded", "seeded", "explicit", "explicit", "explicit", "seeded", "seeded_small", "seeded"],
     ["seeded", "seeded_small", "seeded", "cumulative", "seeded"],
     ["seeded", "strict", "seeded", "explicit", "seeded", "native", "seeded", "reupload", "seeded"],
     ["seeded", "fetch", "seeded", "fetch", "explicit", "explicit", "fetch"],
@@ -76,10 +79,11 @@ def test_deferred_finish_changes_no_result(plan):
     solver = M.Solver(0)
     try:
         want = _stream_of_solves(solver, False, plan)
-        got = _stream_of_solves(solver, True, plan)
-        assert len(got) == len(want)
-        for a, b in zip(got, want):
-            assert a == b, a[0]
+        for level in (1, 2):                                  # 1: deferred finish; 2: two runs per launch as well
+            got = _stream_of_solves(solver, level, plan)
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert a == b, (level, a[0])
         sinks = np.frombuffer(want[-1][1], dtype=np.int64).reshape(-1, 2)
         assert (sinks[:, 1] >= 0).all()                       # every run deposited its winners in ITS row
     finally:
@@ -91,7 +95,7 @@ def test_deferred_finish_on_a_fleet_and_with_timing():
     try:
         probs, seeds = W.fleet_problems(24, depth=10)
         out = []
-        for pipeline in (False, True):
+        for pipeline in (0, 1, 2):
             solver.set_pipeline(pipeline)
             solver.set_timing(1)
             solver.upload(probs, seeds)
@@ -99,16 +103,16 @@ def test_deferred_finish_on_a_fleet_and_with_timing():
             for k in range(4):
                 solver.run_seeded(0, 1024 + 64 * k, M.PREC_FAST)
             runs, k_ms, t_ms = solver.timing(reset=True)
-            assert runs == 4 and 0 < k_ms <= t_ms
+            assert runs == (2 if pipeline == 2 else 4) and 0 < k_ms <= t_ms       # level 2: one pair of events per launch of two runs
             res = solver.fetch()
             out.append([(r.status, r.best_ordinal, r.best_last, traj_array(r).tobytes()) for r in res])
-        assert out[0] == out[1]
+        assert out[0] == out[1] == out[2]
         solver.set_timing(1)
     finally:
         solver.close()
 
 
-@pytest.mark.parametrize("pipeline", [False, True])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_winner_record_sink_carries_the_winners_controls(pipeline):
     """mpc_hip_set_winner_record_sink / mpc_hip_copy_winner_records: (score bits, ordinal) as the plain sink writes
     them, then the winner's clamped controls per level -- the ones in the fetched trajectory, bit for bit -- for every

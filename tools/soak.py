@@ -16,13 +16,16 @@ with torch.cuda.stream(stream):
     N = 20000
     # the deferred finish (argv[1] == "pipeline"): every solve's finish rides in the next solve's rollout launch, reading
     # one half of the double-buffered working memory while the rollouts fill the other
-    s.set_pipeline(len(sys.argv) > 1 and sys.argv[1] == "pipeline")
+    # "pipeline2": also two solves per launch (level 2)
+    LEVEL = {"pipeline": 1, "pipeline2": 2}.get(sys.argv[1] if len(sys.argv) > 1 else "", 0)
+    s.set_pipeline(LEVEL)
     sink = torch.zeros(2 * N, dtype=torch.int64, device="cuda")
     ref_last = None
     for i in range(N):
         s.set_winner_sink(sink[2 * i:2 * i + 2])
         s.run_candidates(d_r, d_t, count, M.PREC_FAST, M.SELECT_LAST_STEP, d_last, d_cum)
         if i % 5000 == 0:
+            s.flush()                                # (level 2: a run without a partner has not been launched yet)
             torch.cuda.synchronize()
             cur = d_last.clone()
             if ref_last is None: ref_last = cur
@@ -35,7 +38,7 @@ with torch.cuda.stream(stream):
     print("config2 x", N, "distinct winners:", len(np.unique(w, axis=0)), w[0], flush=True)
     assert len(np.unique(w, axis=0)) == 1
     # pipelined, alternating candidate sources and sizes: every kind of hand-over between consecutive launches
-    s.set_pipeline(True)
+    s.set_pipeline(max(LEVEL, 1))
     M2 = 6000
     sink2 = torch.zeros(2 * M2, dtype=torch.int64, device="cuda")
     kinds = 4
