@@ -437,11 +437,8 @@ static int launch_pair(mpc_hip_handle *h, const StashedRun *second)
     h->timed[first.slot] = t == &first;
     if (second) h->timed[second->slot] = t == second;
     if (t) h->total_from_k1[t->slot] = 1;                /* the finishes have no dispatch of their own */
-#define LAUNCH_PAIR(SEEDED, PREGEN) \
-    hipExtLaunchKernelGGL((rollout_pair_kernel<SEEDED, PREGEN>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A)
-    if (first.seeded) { if (first.pregen) LAUNCH_PAIR(true, true); else LAUNCH_PAIR(true, false); }
-    else LAUNCH_PAIR(false, false);
-#undef LAUNCH_PAIR
+    if (first.seeded) hipExtLaunchKernelGGL((rollout_pair_kernel<true>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A);
+    else hipExtLaunchKernelGGL((rollout_pair_kernel<false>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A);
     HIP_TRY(hipGetLastError());
     h->n_pend2 = 0;
     h->pend2[h->n_pend2] = first;
@@ -576,10 +573,10 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     if (pairable) {
         const StashedRun rec{RunArgs{d_rud, d_thr, first, count, selection, snap_depth, rel, d_cost_last, d_cost_cum, d_keys, d_snap,
                                      d_pkey, d_pord, d_pcnt, nblk, 0u},
-                             fin, seeded, pregen, timed, lds, h->n_probs, slot};
+                             fin, seeded, timed, lds, h->n_probs, slot};
         h->timed[slot] = false;                                         /* set by the launch that carries the events */
         int s = MPC_OK;
-        if (h->stashed && h->stash.seeded == seeded && h->stash.pregen == pregen && h->stash.n_probs == h->n_probs)
+        if (h->stashed && h->stash.seeded == seeded && h->stash.n_probs == h->n_probs)
             s = launch_pair(h, &rec);
         else {
             if (h->stashed) s = launch_pair(h, nullptr);

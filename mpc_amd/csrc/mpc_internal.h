@@ -102,7 +102,7 @@ struct RunArgs {
 struct StashedRun {
     RunArgs run;
     FinishArgs fin;
-    bool seeded, pregen, timed;
+    bool seeded, timed;
     size_t lds;
     uint32_t n_probs, slot;
 };

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
  * are picked by a workgroup-uniform index into the kernel argument block (scalar loads, one copy of the body). */
 struct PairArgs { RunArgs run[2]; FinishArgs prev[2]; };
 
-template <bool SEEDED, bool PREGEN>
+template <bool SEEDED>
 __global__ __launch_bounds__(256) void rollout_pair_kernel(const DevProblem *__restrict__ probs, const PairArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -632,7 +632,9 @@ __global__ __launch_bounds__(256) void rollout_pair_kernel(const DevProblem *__r
     }
     const uint32_t w = blockIdx.x >= na ? 1u : 0u;
     const RunArgs &R = A.run[w];
-    rollout_body<MPC_PREC_FAST, SEEDED, true, PREGEN>(probs, R.rud, R.thr, R.first, R.count, R.selection, R.rel, R.cost_last, R.cost_cum,
+    /* (seeded sets generate their controls level by level here: PREGEN's 20 KB of LDS per workgroup would not let
+     * eight workgroups share a CU) */
+    rollout_body<MPC_PREC_FAST, SEEDED, true, false>(probs, R.rud, R.thr, R.first, R.count, R.selection, R.rel, R.cost_last, R.cost_cum,
                                                       R.keys, R.snap, R.snap_depth, R.pkey, R.pord, R.pcnt, blockIdx.x - (w ? na : 0u),
                                                       R.nblk, lds);
 }
