@@ -16,11 +16,13 @@
  *                        section 8c documents them ("parity unpinned" for these two)
  *   dubins_curves        dubins_path_sample (A. Walker's Dubins-Curves, published algorithm)
  *
- * PINNING STATUS (see DESIGN.md "Oracle"): the reference cannot be compiled in this image without
- * writing stand-ins for the absent path_planner_common/dubins headers, so there is no oracle/_ref.
- * The restatement is pinned by (1) the reference-run golden vectors recorded in SURVEY.md section 4
- * and section 8c (tests/golden/survey_probe.json) and (2) the properties the reference's own live
- * tests assert (test/test_controller.cpp:396-433).
+ * PINNING STATUS: PARITY UNPINNED (see DESIGN.md "Oracle").  The reference holds no golden numbers for
+ * this path, and it cannot be compiled in this image without writing stand-ins for the absent
+ * path_planner_common/dubins headers, so there is no oracle/_ref.  What anchors the restatement is weaker
+ * than a pin and is checked all the same (tests/test_oracle_golden.py): (1) the outputs SURVEY.md section 4
+ * and section 8c record from the survey session's own build of the reference sources (against a stub header,
+ * without a committed recipe: tests/golden/survey_probe.json is typed in from there) and (2) the properties
+ * the reference's own live tests assert (test/test_controller.cpp:396-433, :467, :384-394).
  */
 #ifndef MPC_ORACLE_H
 #define MPC_ORACLE_H
