@@ -90,6 +90,25 @@ def test_deferred_finish_changes_no_result(plan):
         solver.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_streams_give_the_same_results_at_every_pipeline_level(seed):
+    """40 random steps (every kind of run, fetches in between) at levels 0, 1 and 2: every sink row, every fetched
+    result and the final one are bit for bit the same -- whatever pairs up, rides along or goes alone"""
+    rng = np.random.default_rng(seed)
+    kinds = ["seeded", "seeded", "explicit", "explicit", "seeded_small", "cumulative", "strict", "fetch", "reupload", "native"]
+    plan = [kinds[int(k)] for k in rng.integers(0, len(kinds), 40)]
+    solver = M.Solver(0)
+    try:
+        want = _stream_of_solves(solver, 0, plan)
+        for level in (1, 2):
+            got = _stream_of_solves(solver, level, plan)
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert a == b, (level, a[0], plan)
+    finally:
+        solver.close()
+
+
 def test_deferred_finish_on_a_fleet_and_with_timing():
     solver = M.Solver(0)
     try:
