@@ -537,7 +537,14 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
      * stay small; beyond that the winner is rolled out again by one lane, which is then noise */
     int snap_depth = 0;
     for (uint32_t p = 0; p < h->n_probs; p++) snap_depth = std::max(snap_depth, (int)h->depth[p]);
-    const size_t snap_need = (size_t)h->n_probs * count * snap_slots(snap_depth) * SNAP_FIELDS;     /* every SNAP_STRIDE-th level */
+    /* every level for a run that finishes at once (its K2 then only reads), every 4th for a stream of solves (the
+     * finish rides under the next launch) and where every level would not fit */
+    int snap_shift = pipelined ? SNAP_SHIFT_STREAM : 0;
+    size_t snap_need = (size_t)h->n_probs * count * snap_slots(snap_depth, snap_shift) * SNAP_FIELDS;
+    if (snap_shift == 0 && snap_need * sizeof(double) > MPC_SNAPSHOT_BYTES_MAX) {
+        snap_shift = SNAP_SHIFT_STREAM;
+        snap_need = (size_t)h->n_probs * count * snap_slots(snap_depth, snap_shift) * SNAP_FIELDS;
+    }
     double *d_snap = nullptr;
     if (!use_static && snap_need > 0 && snap_need * sizeof(double) <= MPC_SNAPSHOT_BYTES_MAX) {
         if (int s = ensure_buffer(h, (void **)&wm.d_snap, &wm.cap_snap, sizeof(double) * snap_need)) return s;
@@ -568,11 +575,11 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     h->total_from_k1[slot] = 0;
     if (fuse) h->total_from_k1[h->pend_slot] = 1;          /* that run's finish has no dispatch of its own: hidden in this K1 */
     const FinishArgs fin{h->d_probs, d_rud, d_thr, first, count, selection, fast, (int)uniform, rel, nblk, cpb,
-                         d_pkey, d_pord, d_pcnt, d_keys, d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->winner_sink_words, 0u,
+                         d_pkey, d_pord, d_pcnt, d_keys, d_snap, snap_depth, h->d_winners, h->d_winner_sink, h->winner_sink_words, snap_shift,
                          h->d_results};
     if (pairable) {
         const StashedRun rec{RunArgs{d_rud, d_thr, first, count, selection, snap_depth, rel, d_cost_last, d_cost_cum, d_keys, d_snap,
-                                     d_pkey, d_pord, d_pcnt, nblk, 0u},
+                                     d_pkey, d_pord, d_pcnt, nblk, snap_shift},
                              fin, seeded, timed, lds, h->n_probs, slot};
         h->timed[slot] = false;                                         /* set by the launch that carries the events */
         int s = MPC_OK;
@@ -595,11 +602,11 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     if (uniform) LAUNCH_K1U(PREC, SEEDED, true, false); else LAUNCH_K1U(PREC, SEEDED, false, false)
 #define LAUNCH_K1U(PREC, SEEDED, UNI, FUSE)                                                                   \
     hipExtLaunchKernelGGL((rollout_kernel<PREC, SEEDED, UNI, FUSE>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth,     \
+                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth, snap_shift, \
                        d_pkey, d_pord, d_pcnt, prev)
 #define LAUNCH_K1P(UNI, FUSE)                                                                                 \
     hipExtLaunchKernelGGL((rollout_kernel<MPC_PREC_FAST, true, UNI, FUSE, true>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, d_rud, d_thr, \
-                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth,     \
+                       first, count, selection, rel, d_cost_last, d_cost_cum, d_keys, d_snap, snap_depth, snap_shift, \
                        d_pkey, d_pord, d_pcnt, prev)
     if (fuse && pregen) LAUNCH_K1P(true, true);
     else if (fuse) { if (seeded) LAUNCH_K1U(MPC_PREC_FAST, true, true, true); else LAUNCH_K1U(MPC_PREC_FAST, false, true, true); }

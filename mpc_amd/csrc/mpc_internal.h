@@ -84,7 +84,8 @@ struct FinishArgs {
     double *snap_base;
     int snap_depth;
     uint64_t *winners, *sink;
-    uint32_t sink_words, pad;
+    uint32_t sink_words;
+    int snap_shift;                 /* snapshots hold every 2^shift-th level */
     DevResult *results;
 };
 /* what K1 needs of one run: rollout_pair_kernel (mpc_hip_set_pipeline level 2) takes two of these */
@@ -96,7 +97,8 @@ struct RunArgs {
     double *cost_last, *cost_cum, *keys, *snap;
     uint64_t *pkey, *pord;
     uint32_t *pcnt;
-    uint32_t nblk, pad;
+    uint32_t nblk;
+    int snap_shift;
 };
 /* a run that is prepared but not launched yet (level 2: it waits for a partner) */
 struct StashedRun {

@@ -96,13 +96,14 @@ __device__ inline double clampd(double v, double lo, double hi) { return v < lo 
  * that the LDS waits then have to drain.  base == nullptr = no snapshots. */
 #define SNAP_PAIRS 5
 #define SNAP_FIELDS (2 * SNAP_PAIRS)
-/* Only every SNAP_STRIDE-th level is written (the states after levels S-1, 2S-1, ...: slot (l+1)/S - 1): K2's thread
- * for level l starts from the nearest slot below (or the start state) and integrates the <= S-1 levels in between with
- * the code K1 ran -- the same bits -- all levels in parallel.  Every level (round 1) was 84 MB per config-2 solve,
- * 8x the bytes the problem needs; every 4th is 21 MB for ~7 us more latency of a synchronous solve's finish, and nothing
- * for a stream of solves, whose finish rides under the next rollout launch. */
-#define SNAP_STRIDE 4
-__host__ __device__ inline int snap_slots(int depth) { return depth / SNAP_STRIDE; }
+/* Only every 2^shift-th level is written (the states after levels S-1, 2S-1, ...: slot (l+1)/S - 1): K2's thread for
+ * level l starts from the nearest slot below (or the start state) and integrates the <= S-1 levels in between with the
+ * code K1 ran -- the same bits -- all levels in parallel.  The host picks the stride per run: every level (shift 0) for
+ * a run whose result is wanted at once -- K2 then only reads (6 us instead of 12 on config 2), and nobody counts the 84
+ * MB K1 writes in 39 us; every 4th (shift 2, 21 MB: the problem's own bytes are 12 MB) for a stream of solves, whose
+ * finish rides under the next rollout launch where its extra 6 us cost nothing, and for sets too big for every level. */
+#define SNAP_SHIFT_STREAM 2
+__host__ __device__ inline int snap_slots(int depth, int shift) { return depth >> shift; }
 /* K1's side.  The stores are buffer stores with the WRITE-THROUGH cache policy (sc0 sc1): 94 MB of snapshots per
  * config-2 solve otherwise sit dirty in the XCDs' L2s until the end-of-kernel write-back, which then delays the
  * next dispatch (measured: plain 42.1 us K1 / 58.7 us per solve, nontemporal 40.0 / 56.3, write-through 39.6 / 55.6;
@@ -114,6 +115,8 @@ struct SnapW {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t pair_bytes;         /* 16 * candidates of the problem: distance between consecutive pairs */
     uint32_t lane_off;           /* 16 * this lane's candidate index */
+    uint32_t mask;               /* 2^shift - 1: level l is written when ((l + 1) & mask) == 0, into slot ((l + 1) >> shift) - 1 */
+    int shift;
     bool on;
     __device__ inline void put2(int l, int q, double a, double b) const
     {
@@ -124,10 +127,11 @@ struct SnapW {
     }
 };
 
-__device__ inline SnapW snap_writer(double *problem_base, uint64_t count, int snap_depth, uint64_t i)
+__device__ inline SnapW snap_writer(double *problem_base, uint64_t count, int snap_depth, int shift, uint64_t i)
 {
     SnapW w;
-    const uint64_t bytes = (uint64_t)snap_slots(snap_depth) * SNAP_PAIRS * count * 16;      /* <= MPC_SNAPSHOT_BYTES_MAX (host) */
+    const uint64_t bytes = (uint64_t)snap_slots(snap_depth, shift) * SNAP_PAIRS * count * 16;      /* <= MPC_SNAPSHOT_BYTES_MAX (host) */
+    w.shift = shift; w.mask = (1u << shift) - 1u;
     w.rsrc = __builtin_amdgcn_make_buffer_rsrc(problem_base, 0, (int)(uint32_t)bytes, 0x00020000);
     w.pair_bytes = (uint32_t)(count * 16);
     w.lane_off = (uint32_t)(i * 16);
@@ -139,7 +143,7 @@ __device__ inline SnapW snap_none()
 {
     SnapW w;
     w.rsrc = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
-    w.pair_bytes = 0; w.lane_off = 0; w.on = false;
+    w.pair_bytes = 0; w.lane_off = 0; w.mask = 0; w.shift = 0; w.on = false;
     return w;
 }
 
@@ -186,8 +190,8 @@ __device__ inline void eval_strict(const DevProblem &P, const double *cpL, const
         if (traj)
             traj[l + 1] = mpc_level_state{s.x, s.y, s.h, s.v, s.rpm, s.cmg, s.sog,
                                           clampd(r, -1, 1), clampd(t, 0, 1), cum};
-        if (snap.on && ((l + 1) % SNAP_STRIDE) == 0) {
-            const int q = (l + 1) / SNAP_STRIDE - 1;
+        if (snap.on && ((uint32_t)(l + 1) & snap.mask) == 0) {
+            const int q = ((l + 1) >> snap.shift) - 1;
             snap.put2(q, 0, s.x, s.y); snap.put2(q, 1, s.h, s.v); snap.put2(q, 2, s.rpm, s.cmg);
             snap.put2(q, 3, s.sog, cum); snap.put2(q, 4, last, 0.0);
         }
@@ -252,8 +256,8 @@ __device__ inline void eval_fast(const DevProblem &P, const double *cpL, const d
         if (traj)
             traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta,
                                               r, t, cum);
-        if (snap.on && ((l + 1) % SNAP_STRIDE) == 0) {
-            const int q = (l + 1) / SNAP_STRIDE - 1;
+        if (snap.on && ((uint32_t)(l + 1) & snap.mask) == 0) {
+            const int q = ((l + 1) >> snap.shift) - 1;
             snap.put2(q, 0, s.x, s.y); snap.put2(q, 1, s.sh, s.ch); snap.put2(q, 2, s.v, s.rpm);
             snap.put2(q, 3, cum, last);
         }
@@ -280,7 +284,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
     const uint32_t *__restrict__ pcnt = A.pcnt;
     const double *__restrict__ keys = A.keys;
     double *__restrict__ snap_base = A.snap_base;
-    const int snap_depth = A.snap_depth;
+    const int snap_depth = A.snap_depth, snap_shift = A.snap_shift;
     uint64_t *__restrict__ winners = A.winners, *__restrict__ sink = A.sink;
     const uint32_t sw = A.sink_words;              /* 2: (score bits, ordinal); 2 + 2 * depth: + the winner's controls */
     DevResult *__restrict__ results = A.results;
@@ -385,18 +389,18 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
         }
         return;
     }
-    if (snap_base && snap_slots(snap_depth) > 0 && (keep_fast || !fast)) {
-        /* K1 left every candidate's state after every SNAP_STRIDE-th level in HBM.  One thread per level: start from the
-         * nearest slot below (or the start state) and integrate the <= SNAP_STRIDE - 1 levels in between with K1's own
+    if (snap_base && snap_slots(snap_depth, snap_shift) > 0 && (keep_fast || !fast)) {
+        /* K1 left every candidate's state after every 2^shift-th level in HBM.  One thread per level: start from the
+         * nearest slot below (or the start state) and integrate the < 2^shift levels in between with K1's own
          * code (strict/fast_level_and_score, the flavour K1 ran): the same bits as K1 had in its registers. */
-        const Snap snap{snap_base + (uint64_t)p * snap_slots(snap_depth) * SNAP_FIELDS * count, count, win - first};
+        const Snap snap{snap_base + (uint64_t)p * snap_slots(snap_depth, snap_shift) * SNAP_FIELDS * count, count, win - first};
         const int l = threadIdx.x;
         double *s_tail = (double *)(small + 12);       /* [0] = last, [1] = cum of the last level (words 12, 13 of the small state) */
         if (l < P.depth) {
             const Weights w{P.wd, P.wh, P.ws};
             const Model M = P.model;
-            const int g = (l + 1) / SNAP_STRIDE;           /* slots at or below level l */
-            const int from = g * SNAP_STRIDE;              /* first level to integrate (== l + 1: none) */
+            const int g = (l + 1) >> snap_shift;           /* slots at or below level l */
+            const int from = g << snap_shift;              /* first level to integrate (== l + 1: none) */
             double r = 0, t = 0, cum = 0, last = 0;
             if (fast) {
                 const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
@@ -510,7 +514,7 @@ __device__ __forceinline__ void rollout_body(const DevProblem *__restrict__ prob
                                              uint64_t first, uint64_t count, int selection, double refine_rel,
                                              double *__restrict__ cost_last, double *__restrict__ cost_cum,
                                              double *__restrict__ keys, double *__restrict__ snap_base,
-                                             int snap_depth, uint64_t *__restrict__ pkey,
+                                             int snap_depth, int snap_shift, uint64_t *__restrict__ pkey,
                                              uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt,
                                              const uint32_t bx, const uint32_t n_rollout_blocks, double *lds)
 {
@@ -560,8 +564,8 @@ __device__ __forceinline__ void rollout_body(const DevProblem *__restrict__ prob
         const ControlSource c{rud, thr, count, P.seed, P.last_r, P.last_t,
                               SEEDED ? nullptr : ctlL + threadIdx.x, blockDim.x,
                               (SEEDED && PREGEN) ? genL + threadIdx.x : nullptr};
-        const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_slots(snap_depth) * SNAP_FIELDS * count : nullptr,
-                                       count, snap_depth, i);
+        const SnapW snap = snap_writer(snap_base ? snap_base + (uint64_t)blockIdx.y * snap_slots(snap_depth, snap_shift) * SNAP_FIELDS * count : nullptr,
+                                       count, snap_depth, snap_shift, i);
         double last, cum;
         if (PREC == MPC_PREC_F64) eval_strict<SEEDED, UNIFORM, !SEEDED, PREGEN>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
         else eval_fast<SEEDED, UNIFORM, !SEEDED, PREGEN>(P, cpL, subL, c, first + i, i, last, cum, nullptr, snap);
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
                                                       uint64_t first, uint64_t count, int selection, double refine_rel,
                                                       double *__restrict__ cost_last, double *__restrict__ cost_cum,
                                                       double *__restrict__ keys, double *__restrict__ snap_base,
-                                                      int snap_depth, uint64_t *__restrict__ pkey,
+                                                      int snap_depth, int snap_shift, uint64_t *__restrict__ pkey,
                                                       uint64_t *__restrict__ pord, uint32_t *__restrict__ pcnt,
                                                       const FinishArgs prev)
 {
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
         return;
     }
     rollout_body<PREC, SEEDED, UNIFORM, PREGEN>(probs, rud, thr, first, count, selection, refine_rel, cost_last, cost_cum, keys,
-                                                snap_base, snap_depth, pkey, pord, pcnt, blockIdx.x, n_rollout_blocks, lds);
+                                                snap_base, snap_depth, snap_shift, pkey, pord, pcnt, blockIdx.x, n_rollout_blocks, lds);
 }
 
 /* Two runs in ONE launch (mpc_hip_set_pipeline level 2).  A 65,536-candidate set is one wave per SIMD, and a lone wave
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256) void rollout_pair_kernel(const DevProblem *__r
     /* (seeded sets generate their controls level by level here: PREGEN's 20 KB of LDS per workgroup would not let
      * eight workgroups share a CU) */
     rollout_body<MPC_PREC_FAST, SEEDED, true, false>(probs, R.rud, R.thr, R.first, R.count, R.selection, R.rel, R.cost_last, R.cost_cum,
-                                                      R.keys, R.snap, R.snap_depth, R.pkey, R.pord, R.pcnt, blockIdx.x - (w ? na : 0u),
+                                                      R.keys, R.snap, R.snap_depth, R.snap_shift, R.pkey, R.pord, R.pcnt, blockIdx.x - (w ? na : 0u),
                                                       R.nblk, lds);
 }
 
