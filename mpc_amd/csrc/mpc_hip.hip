@@ -537,9 +537,10 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
      * stay small; beyond that the winner is rolled out again by one lane, which is then noise */
     int snap_depth = 0;
     for (uint32_t p = 0; p < h->n_probs; p++) snap_depth = std::max(snap_depth, (int)h->depth[p]);
-    /* every level for a run that finishes at once (its K2 then only reads), every 4th for a stream of solves (the
-     * finish rides under the next launch) and where every level would not fit */
-    int snap_shift = pipelined ? SNAP_SHIFT_STREAM : 0;
+    /* every level for a run whose K2 is a launch of its own (it then only reads), every 4th where the finish rides under
+     * the next rollout launch (a stream of small fast solves) and where every level would not fit */
+    const bool hidden_finish = pipelined && fast && uniform && block == 64;    /* the runs whose K2 can ride in a later K1 launch */
+    int snap_shift = hidden_finish ? SNAP_SHIFT_STREAM : 0;
     size_t snap_need = (size_t)h->n_probs * count * snap_slots(snap_depth, snap_shift) * SNAP_FIELDS;
     if (snap_shift == 0 && snap_need * sizeof(double) > MPC_SNAPSHOT_BYTES_MAX) {
         snap_shift = SNAP_SHIFT_STREAM;
