@@ -187,3 +187,46 @@ def test_negative_or_non_finite_weights_are_rejected(solver):
     p = _circle_problem(4, W.uniform_substeps())
     p.w_distance, p.w_heading, p.w_speed = 0.0, 0.0, 0.0                    # zeros are fine: everything ties at 0, ordinal 0 wins
     assert solver.eval_seeded(p, W.SEED, 0, 256).best_ordinal == 0
+
+
+def test_misuse_of_the_stream_and_multi_gpu_entry_points_is_refused():
+    """pipeline level out of range, winner records before any run / shallower than a resident problem / of a depth out
+    of range, exact combine with too many shards or a row count that is not a multiple of the resident problems: every
+    one an MPC_ERR_* with a message, none a launch"""
+    import torch
+    s = M.Solver(0)
+    try:
+        with pytest.raises(M.MpcError):
+            s.set_pipeline(3)
+        p = W.config2_problem(depth=6)
+        s.upload([p, p], [1, 2])
+        buf = torch.zeros(4096, dtype=torch.int64, device="cuda")
+        with pytest.raises(M.MpcError):
+            s.copy_winner_records(buf, 6)                     # nothing has run
+        s.run_seeded(0, 256, M.PREC_FAST)
+        with pytest.raises(M.MpcError):
+            s.copy_winner_records(buf, 5)                     # shallower than the problems
+        with pytest.raises(M.MpcError):
+            s.copy_winner_records(buf, M.MAX_DEPTH + 1)
+        with pytest.raises(M.MpcError):
+            s.set_winner_record_sink(buf, 0)
+        out = torch.zeros(64, dtype=torch.int64, device="cuda")
+        with pytest.raises(M.MpcError):
+            s.combine_shards_exact(buf, 65, 2, 6, 0, out)     # a lane per shard: at most 64
+        with pytest.raises(M.MpcError):
+            s.combine_shards_exact(buf, 2, 3, 6, 0, out)      # rows must be solves x problems
+        with pytest.raises(M.MpcError):
+            s.combine_shards_exact(buf, 2, 2, 5, 0, out)      # records shallower than the problems
+        # and the well-formed call right after still works: two shards holding the same records -> the lower shard wins ties
+        s.copy_winner_records(buf[:2 * M.winner_record_words(6)], 6)
+        W6 = M.winner_record_words(6)
+        buf[2 * W6:4 * W6] = buf[:2 * W6]
+        torch.cuda.synchronize()
+        s.combine_shards_exact(buf, 2, 2, 6, 1000, out)
+        s.synchronize()
+        res = s.fetch()
+        o = out[:4].view(2, 2).cpu().numpy()
+        assert [int(o[q, 1]) for q in range(2)] == [r.best_ordinal for r in res]
+        assert s.tied_rows() == 2                             # both rows: two shards at the same fast score
+    finally:
+        s.close()
