@@ -222,12 +222,19 @@ __device__ inline double fast_level_and_score(const DevProblem &P, const Model &
     const double *cpv = cpL + l * CP_STRIDE;
     double cp[CP_STRIDE];
     cp[3] = cpv[3]; cp[4] = cpv[4]; cp[5] = cpv[5]; cp[6] = cpv[6]; cp[7] = cpv[7];
-    /* not the LEAN spellings (mpc_model.h): a candidate's cost must not depend on how its set was supplied or
-     * sized, and config 2 -- one wave per SIMD -- is 0.6 us faster without them */
-    if (UNIFORM) fast_level<0>(s, r, t, row0, P.nsub, M);
-    else if (P.head_uniform) fast_level_head_uniform(s, r, t, subL, P.nsub, M);
-    else fast_level<SUB_STRIDE>(s, r, t, subL, P.nsub, M);
-    return fast_score(cp, s, w, q_last);
+    /* ONE spelling of the fast model everywhere (K1, K2, the pair kernel, the single rollout; the tree expansion uses the
+     * same one): a candidate's cost must not depend on how its set was supplied, sized or scheduled.  It is the LEAN one
+     * (mpc_model.h: three-address Horner steps, the 17-instruction exp) since a stream of solves runs two waves per SIMD
+     * and is VALU-bound like the dense launches: +2 % on configs 2, 4 and 5 alike (round 1's lone-wave kernel was 0.6 us
+     * FASTER with the compiler's spelling, whose copies filled dependent-issue bubbles).  Costs moved by <= 9e-15
+     * relative, no winner changed. */
+#ifndef MPC_FAST_LEAN
+#define MPC_FAST_LEAN true
+#endif
+    if (UNIFORM) fast_level<0, MPC_FAST_LEAN>(s, r, t, row0, P.nsub, M);
+    else if (P.head_uniform) fast_level_head_uniform<MPC_FAST_LEAN>(s, r, t, subL, P.nsub, M);
+    else fast_level<SUB_STRIDE, MPC_FAST_LEAN>(s, r, t, subL, P.nsub, M);
+    return fast_score<MPC_FAST_LEAN>(cp, s, w, q_last);
 }
 
 template <bool SEEDED, bool UNIFORM = false, bool STAGED = false, bool PREGEN = false>
@@ -753,8 +760,8 @@ __global__ __launch_bounds__(64) void rollout_one_kernel(const DevProblem *__res
         const double *q_last = subL + (P.nsub - 1) * SUB_STRIDE;
         for (int l = 0; l < P.depth; l++) {
             const double r = controls[l], t = controls[MPC_MAX_DEPTH + l];
-            fast_level(s, r, t, subL, P.nsub, P.model);
-            last = fast_score(cpL + l * CP_STRIDE, s, w, q_last);
+            fast_level<SUB_STRIDE, MPC_FAST_LEAN>(s, r, t, subL, P.nsub, P.model);
+            last = fast_score<MPC_FAST_LEAN>(cpL + l * CP_STRIDE, s, w, q_last);
             cum += last;
             R.traj[l + 1] = fast_to_level_state(cpL + l * CP_STRIDE, q_last, s.x, s.y, s.sh, s.ch, s.v, s.rpm, s.delta,
                                                 r, t, cum);

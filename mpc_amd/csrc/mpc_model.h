@@ -256,10 +256,11 @@ __device__ inline double fma3(double a, double b, double c)
     return d;
 }
 
-/* LEAN chooses between the two spellings of a Horner step: the compiler's (mov + fmac) for kernels that run one wave
- * per SIMD (config 2: 36.1 us vs 36.7 us with fma3), fma3 for launches that fill the SIMDs (4 M candidates: -2 %,
- * tree expansion: -3 %).  The candidate-set kernels all use ONE spelling (the compiler's), so that a candidate's
- * cost does not depend on the size of the set it came in; the tree expansion uses the lean one. */
+/* LEAN chooses between the two spellings of a Horner step: the compiler's (mov + fmac) or fma3.  While config 2 ran one
+ * wave per SIMD the compiler's was faster there (36.1 us vs 36.7 us with fma3) and fma3 only where the SIMDs were full
+ * (4 M candidates: -2 %, tree expansion: -3 %); now that a stream of solves runs two waves per SIMD, every device
+ * kernel uses the lean one (MPC_FAST_LEAN in mpc_kernels.h) -- one spelling, so that a candidate's cost does not depend
+ * on the size of the set it came in. */
 template <bool LEAN>
 __device__ inline double horner(double p, double x, double c) { return LEAN ? fma3(p, x, c) : fma(p, x, c); }
 

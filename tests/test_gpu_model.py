@@ -51,6 +51,8 @@ def oracle_hull():
 
 @pytest.mark.parametrize("explicit_default", [False, True])
 def test_default_hull_gives_the_bits_of_the_compile_time_constants(explicit_default):
+    """The strict and tree digests are those of the build with compile-time model constants (commit 74424a6); the fast
+    candidate-set digests were re-recorded when the fast model's spelling changed (the fixture's "provenance")."""
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "gpu_bits_default_hull.json")))["digests"]
     setup = (lambda s: s.set_model(M.default_model())) if explicit_default else None
     got = _gpu_bits().digests(M, W, setup)

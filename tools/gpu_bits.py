@@ -5,8 +5,9 @@ hull reproduces the results the library gave before mpc_hip_set_model existed" (
     python tools/gpu_bits.py [--lib path/to/libmpc_hip.so] > tests/golden/gpu_bits_default_hull.json
 
 tests/golden/gpu_bits_default_hull.json was written by this script on an MI355X with --lib pointing at a build of
-commit 74424a6 (the last one with compile-time model constants).  The test runs the same function on the current
-library.  Every value is a SHA-256 of raw float64/uint64 bytes, or an exact integer."""
+commit 74424a6 (the last one with compile-time model constants); its strict and tree entries still are those digests.
+The fast candidate-set entries were re-recorded with the current library when the fast model's spelling changed (the
+file's "provenance" says which and why).  The test runs the same function on the current library.  Every value is a SHA-256 of raw float64/uint64 bytes, or an exact integer."""
 import argparse
 import hashlib
 import json
