@@ -80,12 +80,13 @@ def measured_valu(k1_seconds, spl=1):
     out = {"sq_insts_valu_per_launch": insts, "lane_issue_frac": insts * 64 / (k1_seconds * 256 * 4 * 16 * 2.4e9),
            "source": "profiles/r02_pmc_summary.json (SQ_INSTS_VALU) / this run's kernel time"}
     try:        # hardware-counted FP64 operations (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 lanes, FMA = 2 FLOP)
-        for ln in open(os.path.join(ROOT, "profiles", "r02_fp64_flop_counters.txt")):
-            if ln.startswith("config2 |"):
-                flop = float(ln.split("|")[5]) * spl            # (that table is per solve: its probe runs one solve per launch)
-                out["counted_fp64_flop_per_launch"] = flop
-                out["counted_fp64_tflops"] = flop / k1_seconds / 1e12
-                out["counted_fp64_frac_of_peak"] = flop / k1_seconds / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
+        rows = {ln.split("|")[0].strip(): float(ln.split("|")[5])
+                for ln in open(os.path.join(ROOT, "profiles", "r02_fp64_flop_counters.txt")) if ln.startswith("config2")}
+        # "config2_pair": counted on the two-solve launch itself; "config2": on a one-solve launch
+        flop = rows["config2_pair"] if spl == 2 and "config2_pair" in rows else rows["config2"] * spl
+        out["counted_fp64_flop_per_launch"] = flop
+        out["counted_fp64_tflops"] = flop / k1_seconds / 1e12
+        out["counted_fp64_frac_of_peak"] = flop / k1_seconds / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
     except Exception:
         pass
     return out

@@ -357,9 +357,14 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
  * writes and K2 reads is double-buffered (h->wm[2]) so that K1 of solve n+1 never overwrites what K2 of solve n reads. */
 static int launch_pair(mpc_hip_handle *h, const StashedRun *second);
 
+/* K2's workgroup: 256 lanes reduce up to 1024 workgroup triples per trip; a problem with few of them (a fleet: 32 per
+ * vessel) gets ONE wave -- its finish is one lane rolling the winner out again, and 4096 such workgroups of four waves
+ * took 0.25 ms where 4096 single waves share the SIMDs four at a time */
+static inline uint32_t finish_block(uint32_t nblk) { return nblk <= 256 ? 64u : 256u; }
+
 static int finish_standalone(mpc_hip_handle *h, const StashedRun &r)
 {
-    const dim3 grid(r.n_probs), blk(256);
+    const dim3 grid(r.n_probs), blk(finish_block(r.fin.nblk));
     if (r.seeded) hipLaunchKernelGGL((finish_kernel<true>), grid, blk, 0, h->stream, r.fin);
     else hipLaunchKernelGGL((finish_kernel<false>), grid, blk, 0, h->stream, r.fin);
     HIP_TRY(hipGetLastError());
@@ -371,7 +376,7 @@ static int flush_pairs(mpc_hip_handle *h)
 {
     if (h->stashed) { if (int s = launch_pair(h, nullptr)) return s; }      /* a run without a partner goes alone */
     if (h->n_pend2 == 2) {                                                  /* the two runs of one launch: one launch for both */
-        const dim3 grid(h->pend2[0].n_probs, 2), blk(256);                  /* (they write different result buffers) */
+        const dim3 grid(h->pend2[0].n_probs, 2), blk(finish_block(std::max(h->pend2[0].fin.nblk, h->pend2[1].fin.nblk)));   /* (they write different result buffers) */
         if (h->pend2[0].seeded) hipLaunchKernelGGL((finish2_kernel<true>), grid, blk, 0, h->stream, h->pend2[0].fin, h->pend2[1].fin);
         else hipLaunchKernelGGL((finish2_kernel<false>), grid, blk, 0, h->stream, h->pend2[0].fin, h->pend2[1].fin);
         HIP_TRY(hipGetLastError());
@@ -388,7 +393,7 @@ static int flush_pending(mpc_hip_handle *h)
     if (!h->pending) return MPC_OK;
     hipEvent_t *ev = &h->ev[4 * h->pend_slot];
     hipEvent_t k2a = h->pend_timed ? ev[2] : nullptr, k2b = h->pend_timed ? ev[3] : nullptr;
-    const dim3 grid(h->pend_n_probs), blk(256);
+    const dim3 grid(h->pend_n_probs), blk(finish_block(h->pend.nblk));
     if (h->pend_seeded) hipExtLaunchKernelGGL((finish_kernel<true>), grid, blk, 0, h->stream, k2a, k2b, 0, h->pend);
     else hipExtLaunchKernelGGL((finish_kernel<false>), grid, blk, 0, h->stream, k2a, k2b, 0, h->pend);
     h->pending = false;
@@ -555,7 +560,9 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
     const uint32_t slot = (uint32_t)(h->runs % TIMING_RING);
     hipEvent_t *ev = &h->ev[4 * slot];
     /* the pending finish rides along when this launch has a variant for it: fast uniform rollouts in one-wave
-     * workgroups (every throughput stream of small sets: config 2), the same kind of candidate source, the same batch */
+     * workgroups (every throughput stream of small sets: config 2), the same kind of candidate source, the same batch.
+     * (Dense launches gain nothing from it: a finish workgroup among 256-lane rollout workgroups holds four wave slots
+     * for as long as a rollout workgroup does -- config 5 measured 15.11 ms fused against 15.07 ms with its own launch.) */
     const bool fuse = pipelined && !pairable && h->pending && fast && uniform && block == 64 && h->pend_seeded == seeded &&
                       h->pend_n_probs == h->n_probs;
     if (h->pending && !fuse) { if (int s = flush_pending(h)) return s; }
