@@ -321,7 +321,7 @@ int         mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_ga
  * instruction every ~6.2 cycles where the SIMD could take one every 4 -- the second wave can only come from another
  * solve.  A run that can pair up (MPC_PREC_FAST, uniform substeps, fewer than 2^20 candidates) is only PREPARED by its
  * call and goes to the GPU together with the next such run, in one dispatch that also carries the finish workgroups of
- * the two runs before (+17 % on a stream of 65,536-candidate solves).  What changes for the caller: the device arrays
+ * the two runs before (+10-15 % on a stream of 65,536-candidate solves).  What changes for the caller: the device arrays
  * a run reads and writes (controls, cost outputs, winner sink) are used from the stream position of the NEXT run -- or
  * of the call that asks for results, which sends a run without a partner alone -- so they must stay as they are
  * until then; everything else is as at level 1, results bit for bit. */
