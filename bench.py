@@ -233,6 +233,8 @@ def main():
         # a stream of solves: each run's finish rides in the next run's rollout launch (one dispatch per solve); the
         # results are bit for bit those of the two-kernel form (tests/test_gpu_pipeline.py)
         level = 0 if args.no_pipeline else args.pipeline_level
+        if level == 2 and args.steps % 2:
+            level = 1          # an odd region would end in a one-solve launch and blur the per-launch kernel time: one solve per launch then
         solver.set_pipeline(level)
         # solves per rollout launch: level 2 pairs the one-wave-per-SIMD solves of config 2 (fast precision) and nothing else
         spl = 2 if (level == 2 and args.workload == "config2" and prec == M.PREC_FAST) else 1
