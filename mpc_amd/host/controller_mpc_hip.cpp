@@ -140,12 +140,17 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
     int status;
     {
         Lease lease;
-        /* MPC_HIP_TREE_PRECISION=fast: expand with the streamlined model; the strict model still decides every level
-         * and the returned states are the strict path's (same leaf, same bits, sooner at depth >= 6) */
-        static const int precision = [] {
+        /* Which model EXPANDS the tree; whichever it is, the strict model decides every level and the returned states
+         * are the strict path's (same leaf, same bits: tests/test_gpu_tree.py).  The streamlined model is sooner from
+         * depth 6 on (depth 7: 7.7 ms against 18 ms), the strict one below (depth 4: 0.11 ms against 0.19 ms), so the
+         * plan's length chooses; MPC_HIP_TREE_PRECISION=fast|strict (or f64) in the environment overrides. */
+        static const int forced = [] {
             const char *e = getenv("MPC_HIP_TREE_PRECISION");
-            return (e && std::string(e) == "fast") ? MPC_PREC_FAST : MPC_PREC_F64;
+            if (e && std::string(e) == "fast") return (int)MPC_PREC_FAST;
+            if (e && (std::string(e) == "strict" || std::string(e) == "f64")) return (int)MPC_PREC_F64;
+            return -1;
         }();
+        const int precision = forced >= 0 ? forced : (maxIterations > 5 ? (int)MPC_PREC_FAST : (int)MPC_PREC_F64);
         status = mpc_hip_solve_tree(lease.h, &problem, maxIterations, precision, poll, &ctx, endTime, 0, nullptr, &result);
     }
     if (ctx.cancelled) return {};                                                             /* :83-86 */

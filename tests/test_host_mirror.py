@@ -53,7 +53,8 @@ def test_drop_in_compiles_with_the_references_own_flags(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f64", "fast"])
+@pytest.mark.parametrize("precision", ["f64", "fast", "auto"])
 def test_controller_mpc_on_gpu(precision):
-    """the same assertions (equality with the oracle's tree search included) whichever model expands the tree"""
+    """the same assertions (equality with the oracle's tree search included) whichever model expands the tree; auto =
+    the drop-in's default: the plan's length chooses"""
     _run("gpu", 110, {"MPC_HIP_TREE_PRECISION": precision})
