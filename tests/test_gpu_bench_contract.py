@@ -41,6 +41,18 @@ def test_default_line_has_the_contract_keys():
     assert d["value"] > 1e11                                       # north_star's floor on one MI355X
     assert d["p50_solve_latency_ms"] < 5.0                         # ... and its latency bound
     assert d["config"]["deferred_finish"] is True
+    # the default stream of config-2 solves: two per rollout launch, and the roofline counts a launch as two solves
+    assert d["config"]["pipeline_level"] == 2 and d["config"]["solves_per_launch"] == 2
+    assert r["kernel"] == "rollout_pair_kernel" and r["solves_per_launch"] == 2
+    assert r["algorithmic_flop_per_launch"] == 2 * 65536 * 20 * (54 * 20 + 21)
+    # the kernel's time (HIP events on the dispatches) accounts for the region: 20 launches of two solves
+    assert 0.85 * d["ms_per_step"] <= d["rollout_kernel_ms"] / 2 <= 1.05 * d["ms_per_step"]
+
+
+def test_an_odd_region_runs_one_solve_per_launch():
+    d = _bench("--steps", "41", "--warmup", "5", "--no-cpu-baseline")
+    assert d["config"]["pipeline_level"] == 1 and d["config"]["solves_per_launch"] == 1
+    assert d["roofline"]["kernel"] == "rollout_kernel" and d["roofline"]["algorithmic_flop_per_launch"] == 65536 * 20 * (54 * 20 + 21)
 
 
 def test_two_kernel_form_and_rccl_rehearsal_choose_the_same_control():
