@@ -283,6 +283,19 @@ def main():
         # (the ranks agree on the number of regions: every dt above is already the max over the ranks)
         elapsed = float(np.median(regions))
         runs, k1_ms_sum, total_ms_sum = solver.timing(reset=True)
+        # for the record: the same regions with ONE solve per launch (pipeline level 1), not part of `value`
+        one_per_launch = None
+        if spl == 2:
+            solver.set_pipeline(1)
+            solver.set_timing(0)
+            for _ in range(4):
+                step()
+            solver.flush()
+            alt = [timed_region()[0] for _ in range(9)]
+            one_per_launch = {"value": world * n_problems * count * depth * problem.n_substeps * args.steps / float(np.median(alt)),
+                              "ms_per_step": float(np.median(alt)) / args.steps * 1e3, "regions": len(alt),
+                              "note": "mpc_hip_set_pipeline level 1: deferred finish only"}
+            solver.set_pipeline(level)
         res = solver.fetch()[0]
         solver.set_pipeline(False)  # the latency loop is one synchronous solve at a time
         solver.set_timing(0)       # the latency loop below is timed by the host clock: no events on its dispatches (~5 us each)
@@ -333,6 +346,7 @@ def main():
                                        ("problem shards, no collective" if world > 1 else "single GPU"))},
             "clock_ramp_s": args.ramp_seconds if args.workload == "config2" else 0.0,
             "p50_solve_latency_ms": p50,
+            "one_solve_per_launch": one_per_launch,
             "rollout_kernel_ms": k1_ms,
             "kernel_timing": "HIP events attached to %d rollout dispatches of the %d timed solves (every %d-th solve's; a dispatch "
                              "holds %d solve%s)" % (runs, args.steps * len(regions), max(1, min(args.timing_period, args.steps)), spl,
