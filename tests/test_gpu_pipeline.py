@@ -50,6 +50,8 @@ def _stream_of_solves(solver, pipeline, plan):
         elif step == "reupload":
             solver.upload([p], [W.SEED + k])
             solver.run_seeded(0, n, M.PREC_FAST)
+        elif step == "static":                                # the entry point that allocates nothing never defers
+            solver.run_seeded_static(k * 1000, 2048, M.PREC_FAST)
         elif step == "fetch":
             r = solver.fetch()[0]
             seen.append(("fetch", r.best_ordinal, r.best_last, r.best_cumulative, traj_array(r).tobytes()))
@@ -95,7 +97,7 @@ def test_random_streams_give_the_same_results_at_every_pipeline_level(seed):
     """40 random steps (every kind of run, fetches in between) at levels 0, 1 and 2: every sink row, every fetched
     result and the final one are bit for bit the same -- whatever pairs up, rides along or goes alone"""
     rng = np.random.default_rng(seed)
-    kinds = ["seeded", "seeded", "explicit", "explicit", "seeded_small", "cumulative", "strict", "fetch", "reupload", "native"]
+    kinds = ["seeded", "seeded", "explicit", "explicit", "seeded_small", "cumulative", "strict", "fetch", "reupload", "native", "static"]
     plan = [kinds[int(k)] for k in rng.integers(0, len(kinds), 40)]
     solver = M.Solver(0)
     try:
