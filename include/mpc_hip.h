@@ -49,7 +49,8 @@ typedef enum {
     /* "FP32 mode" of BASELINE.json: the fast kernel.  State is integrated in FP64 (MI355X runs FP64 vector
      * math at half the FP32 rate) with the model algebraically streamlined: heading carried as (sin, cos)
      * and advanced by a polynomial rotation, divisions by reciprocals, reciprocal-sqrt + Newton, FP32
-     * atan2 on an FP64 cross/dot pair.  Contract: per-candidate cost within 1e-5 relative of the reference
+     * atan2 on an FP64 cross/dot pair.  Contract: per-candidate cost within 1e-5 relative of the reference (relative
+     * to max(|cost|, 1 % of the sum of the weights): a cost that is one cancelling difference has no relative accuracy)
      * (measured: far tighter), and the SAME chosen candidate, guaranteed by re-evaluating every
      * candidate within MPC_REFINE_REL of the minimum with the strict kernel. */
     MPC_PREC_FAST = 0,

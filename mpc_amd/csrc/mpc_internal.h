@@ -69,6 +69,16 @@ struct LevelPtrs {
     uint32_t *parent, *count, *offset;
 };
 
+/* The near-tie window above a minimum score m: everything up to m (1 + rel) -- but never narrower than rel x 1 % of the
+ * weights' sum.  With w_distance = 0 a minimum can be a lone |reference - actual| that cancels to 1e-4 of its operands;
+ * the fast model's error is a fraction of the OPERANDS (tools/fuzz_random_problems.py: <= 2.9e-7 of max(|cost|, that
+ * floor)), so a window measured against such an m alone would be narrower than the error it has to cover. */
+__host__ __device__ inline double mpc_refine_limit(double m, double rel, double wd, double wh, double ws)
+{
+    const double floor = 0.01 * (wd + wh + ws);
+    return m + (m > floor ? m : floor) * rel;
+}
+
 /* everything K2 needs, as one record: the standalone kernel takes it as its argument, and a rollout launch that also
  * finishes the PREVIOUS solve (FUSE, below) carries that solve's record next to its own arguments */
 struct FinishArgs {

@@ -343,7 +343,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
     /* 2. fast mode: the candidates within refine_rel of the minimum */
     if (fast && k < KEY_INF) {
         const double m = __longlong_as_double((long long)k);
-        const double limit = m + m * refine_rel;
+        const double limit = mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws);
         auto consider = [&](uint32_t j, uint64_t key, uint64_t ord, uint32_t near) {
             if (__longlong_as_double((long long)key) > limit) return;
             if (near <= 1) {
@@ -591,7 +591,7 @@ __device__ __forceinline__ void rollout_body(const DevProblem *__restrict__ prob
     if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
     __syncthreads();
     const double m = __longlong_as_double((long long)red[8]);
-    const bool near = (i < count) && (mykey <= m + m * refine_rel);
+    const bool near = (i < count) && (mykey <= mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws));
     const uint32_t wave_n = (uint32_t)__popcll(__ballot(near));
     if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);
     __syncthreads();
@@ -707,7 +707,9 @@ __global__ __launch_bounds__(64) void combine_exact_kernel(const DevProblem *__r
     for (int m = 32; m >= 1; m >>= 1) kmin = min(kmin, (uint64_t)__shfl_xor((unsigned long long)kmin, m, 64));
     if (refine_rel >= 0.0 && kmin < KEY_INF) {
         const double m = __longlong_as_double((long long)kmin);
-        const bool near = mine && reported != ~0ull && __longlong_as_double((long long)key) <= m + m * refine_rel;
+        const DevProblem &Pw = probs[row % n_probs];
+        const bool near = mine && reported != ~0ull &&
+                          __longlong_as_double((long long)key) <= mpc_refine_limit(m, refine_rel, Pw.wd, Pw.wh, Pw.ws);
         const uint32_t n_near = (uint32_t)__popcll(__ballot(near));
         if (n_near > 1 && s == 0) atomicAdd(tied_rows, 1u);            /* for reporting */
         if (n_near > 1 && near) {

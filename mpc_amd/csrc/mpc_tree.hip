@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
     __syncthreads();
     const double m = __longlong_as_double((long long)red[8]);
-    const double limit = m + m * refine_rel;
+    const double limit = mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws);
     uint32_t mine = 0;
 #pragma unroll
     for (uint32_t i = 0; i < EXPAND_TILES; i++) mine += keys[i] <= limit && keys[i] < __longlong_as_double((long long)KEY_INF);
@@ -478,7 +478,7 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
         return;
     }
     const double m = __longlong_as_double((long long)k);
-    const double limit = m + m * refine_rel;
+    const double limit = mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws);
     uint32_t overflow = 0;
     for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) {
         if (__longlong_as_double((long long)pkey[j]) > limit) continue;

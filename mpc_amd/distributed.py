@@ -221,7 +221,7 @@ def combine_winners_exact_device(solver, depth, ordinal_stride=0, group=None):
     return out
 
 
-def combine_winners_exact(winners, ordinal_offset, strict_score, group=None, refine_rel=1.0e-6):
+def combine_winners_exact(winners, ordinal_offset, strict_score, group=None, refine_rel=1.0e-6, floor=0.0):
     """The fast mode's cross-shard decision made exact.  Inside a shard, candidates within MPC_REFINE_REL of the
     shard's minimum are already decided by the strict model; ACROSS shards the packed winners carry fast scores, which
     are only good to ~1e-7.  Here the winners are all-gathered; wherever the best two shards of a problem lie within
@@ -242,7 +242,9 @@ def combine_winners_exact(winners, ordinal_offset, strict_score, group=None, ref
     g = gathered.cpu().numpy()
     keys = g[:, :, 0].view(np.float64)                              # non-negative scores
     kmin = keys.min(axis=0)
-    near = keys <= kmin * (1.0 + refine_rel)                        # [world, P]; +inf rows stay out unless all are
+    # the window of mpc_refine_limit (mpc_internal.h); floor = 1 % of the problem's weights' sum (scalar or [P])
+    with np.errstate(invalid="ignore"):
+        near = keys <= kmin + np.maximum(kmin, floor) * refine_rel  # [world, P]; +inf rows stay out unless all are
     near &= np.isfinite(keys)
     tied = np.flatnonzero(near.sum(axis=0) > 1)
     strict = torch.full((P,), I64_MAX, dtype=torch.int64, device=w.device)
