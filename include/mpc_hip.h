@@ -56,7 +56,9 @@ typedef enum {
     MPC_PREC_FAST = 0,
     /* "FP64 validation mode": the reference's operation order statement by statement, no FMA contraction,
      * IEEE sqrt, correctly rounded divisions, < 1-ulp sin/cos/atan2/exp.  Contract: cost
-     * within 1e-12 relative of the reference (measured 1.4e-14), same argmin. */
+     * within 1e-12 relative of the reference (measured 1.4e-14; relative to max(|cost|, 1 % of the weights' sum)), same
+     * argmin -- up to candidates whose scores differ by an ulp or two, which resolve as ONE libm would and not
+     * necessarily as the reference's own did (its sin/cos/atan2/exp are glibc's, chosen by CPU at load time). */
     MPC_PREC_F64 = 1
 } mpc_precision;
 
