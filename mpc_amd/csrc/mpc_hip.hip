@@ -354,7 +354,8 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
  * A run is K1 (rollouts) + K2 (finish).  With the pipeline on, a run enqueues only K1 and leaves its K2 PENDING; the
  * next run's K1 launch carries it as one extra workgroup per problem (rollout_kernel<.., FUSE>), and any call that
  * needs the results (fetch, winners, upload, synchronize, ...) launches it on its own first.  Working memory that K1
- * writes and K2 reads is double-buffered (h->wm[2]) so that K1 of solve n+1 never overwrites what K2 of solve n reads. */
+ * writes and K2 reads is double-buffered (h->wm[0..1]; level 2 rotates over all four sets) so that K1 of solve n+1 never
+ * overwrites what K2 of solve n reads. */
 static int launch_pair(mpc_hip_handle *h, const StashedRun *second);
 
 /* K2's workgroup: 256 lanes reduce up to 1024 workgroup triples per trip; a problem with few of them (a fleet: 32 per
