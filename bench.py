@@ -119,8 +119,8 @@ def main():
     ap.add_argument("--combine-batch", type=int, default=64,
                     help="solves per all-gather of the shard winners (multi-GPU runs)")
     ap.add_argument("--repeats", type=int, default=0,
-                    help="how many times the K-step region is timed (the median region is reported); 0 = until 50 ms are "
-                         "covered, at most 64 regions")
+                    help="how many times the K-step region is timed (the median region is reported); 0 = until 0.5 s are "
+                         "covered, at most 2000 regions")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="two kernels per solve (rollouts, finish) instead of the deferred finish (mpc_hip_set_pipeline)")
     ap.add_argument("--pipeline-level", type=int, choices=[0, 1, 2], default=2,
@@ -278,8 +278,8 @@ def main():
         while True:
             dt, combined = timed_region()
             regions.append(dt)
-            if (len(regions) >= repeats) if repeats > 0 else (sum(regions) >= 0.05 or len(regions) >= 64):
-                break                                               # auto: at least 50 ms in all, at most 64 regions
+            if (len(regions) >= repeats) if repeats > 0 else (sum(regions) >= 0.5 or len(regions) >= 2000):
+                break                                               # auto: at least 0.5 s in all, at most 2000 regions
         # (the ranks agree on the number of regions: every dt above is already the max over the ranks)
         elapsed = float(np.median(regions))
         runs, k1_ms_sum, total_ms_sum = solver.timing(reset=True)
