@@ -21,7 +21,15 @@ class VehicleState
 {
 public:
     /* rpm follows from the speed, VehicleState.h:20-22; the reference leaves the two derived members unset */
-    VehicleState(State s) : rpm(mpc::rpm_from_speed(s.speed(), mpc::default_model())), courseMadeGood(0), speedOverGround(0), state(s) {}
+    VehicleState(State s) : rpm(mpc::rpm_from_speed(s.speed(), hull())), courseMadeGood(0), speedOverGround(0), state(s) {}
+
+    /* The boat.  The reference's 11 model parameters are compile-time constants (VehicleState.h:86-96) under the note
+     * "should allow setting of boat characteristics" (:84); here they are one process-wide mpc::Model -- like constants,
+     * the same for every VehicleState, so CurrentEstimator and getStateAfterCurrentControl follow without any change --
+     * whose default is the reference's hull, bit for bit.  Set it before the controller runs (it is read without a
+     * lock, as constants are); mpc_amd/host/hull.h sets it together with the device side's (mpc_hip_set_model). */
+    static const mpc::Model& hull() { return hullStorage(); }
+    static void setHull(const mpc::Model& m) { hullStorage() = m; }
 
     VehicleState simulate(double rudder, double throttle, double t) const
     {
@@ -35,7 +43,7 @@ public:
         double rows[SUB_STRIDE * kMaxSubsteps];
         int n = 0;
         VehicleState out(*this);
-        const mpc::Model hull = mpc::default_model();          /* the reference's compile-time hull, VehicleState.h:86-101 */
+        const mpc::Model hull = VehicleState::hull();          /* default: the reference's compile-time hull, VehicleState.h:86-101 */
         mpc::Veh v{state.x(), state.y(), state.heading(), state.speed(), rpm, courseMadeGood, speedOverGround};
         double elapsed = state.time();
         while (t > 0) {
@@ -61,6 +69,7 @@ public:
 
 private:
     static constexpr int kMaxSubsteps = 64;
+    static mpc::Model& hullStorage() { static mpc::Model m = mpc::default_model(); return m; }
 };
 
 #endif

@@ -30,52 +30,84 @@
 #include <utility>
 #include <vector>
 
-#include "controller.h"
-#include "../../include/mpc_hip.h"
+#include "controller.h"      /* the reference's own header once this file sits in its src/  */
+#include "mpc_hip.h"         /* from the include path: -I<this repository>/include */
+#include "controller_mpc_hip.h"
 
 namespace {
 
-/* a pool of handles on device 0 (MPC_HIP_DEVICE overrides); one checked out per running solve */
+/* a pool of handles on device 0 (MPC_HIP_DEVICE overrides); one checked out per running solve.  The pool also holds the
+ * hull the solves run with (mpc_controller_set_hull; default: the reference's constants, VehicleState.h:86-96): a handle
+ * whose hull is older than the pool's gets mpc_hip_set_model when it is next checked out. */
 class HandlePool
 {
 public:
-    mpc_hip_handle* acquire()
+    struct Entry { mpc_hip_handle* h; unsigned long hull; };
+
+    Entry acquire()
     {
+        Entry e{nullptr, 0};
+        mpc_model hull;
+        unsigned long want;
         {
             std::lock_guard<std::mutex> lock(m_Mutex);
-            if (!m_Free.empty()) { mpc_hip_handle* h = m_Free.back(); m_Free.pop_back(); return h; }
+            if (!m_Free.empty()) { e = m_Free.back(); m_Free.pop_back(); }
+            hull = m_Hull; want = m_HullGeneration;
         }
-        int device = 0;
-        if (const char* e = std::getenv("MPC_HIP_DEVICE")) device = std::atoi(e);
-        mpc_hip_handle* h = nullptr;
-        const int s = mpc_hip_create(device, nullptr, &h);
-        if (s != MPC_OK) throw std::runtime_error(std::string("mpc_hip_create: ") + mpc_hip_status_string(s) + ": " + mpc_hip_last_error());
-        /* a controller wants latency, not kernel timings: events on the dispatches cost ~30 us of a 90-us solve */
-        if (!std::getenv("MPC_HIP_TIMING")) mpc_hip_set_timing(h, 0);
-        return h;
+        if (!e.h) {
+            int device = 0;
+            if (const char* env = std::getenv("MPC_HIP_DEVICE")) device = std::atoi(env);
+            const int s = mpc_hip_create(device, nullptr, &e.h);
+            if (s != MPC_OK) throw std::runtime_error(std::string("mpc_hip_create: ") + mpc_hip_status_string(s) + ": " + mpc_hip_last_error());
+            /* a controller wants latency, not kernel timings: events on the dispatches cost ~30 us of a 90-us solve */
+            if (!std::getenv("MPC_HIP_TIMING")) mpc_hip_set_timing(e.h, 0);
+        }
+        if (e.hull != want) {
+            const int s = mpc_hip_set_model(e.h, &hull, 1);
+            if (s != MPC_OK) {
+                const std::string why = std::string("mpc_hip_set_model: ") + mpc_hip_status_string(s) + ": " + mpc_hip_last_error();
+                release(e);
+                throw std::runtime_error(why);
+            }
+            e.hull = want;
+        }
+        return e;
     }
-    void release(mpc_hip_handle* h)
+    void release(Entry e)
     {
         std::lock_guard<std::mutex> lock(m_Mutex);
-        m_Free.push_back(h);
+        m_Free.push_back(e);
     }
-    ~HandlePool() { for (auto* h : m_Free) mpc_hip_destroy(h); }
+    void setHull(const mpc_model& m)
+    {
+        std::lock_guard<std::mutex> lock(m_Mutex);
+        m_Hull = m;
+        m_HullGeneration++;
+    }
+    HandlePool() { mpc_hip_default_model(&m_Hull); }
+    /* no destructor on purpose: see pool() */
 
 private:
     std::mutex m_Mutex;
-    std::vector<mpc_hip_handle*> m_Free;
+    std::vector<Entry> m_Free;
+    mpc_model m_Hull;
+    unsigned long m_HullGeneration = 0;      /* 0 = the library's default hull: a new handle already has it */
 };
 
+/* The pool is never destroyed: a static object's destructor would call mpc_hip_destroy during static teardown, whose
+ * order against the HIP runtime's own teardown is unspecified (hipFree on a runtime that is already gone).  The handles'
+ * device memory goes back to the driver with the process, as all device memory does. */
 HandlePool& pool()
 {
-    static HandlePool p;
-    return p;
+    static HandlePool* p = new HandlePool;
+    return *p;
 }
 
 struct Lease {
+    HandlePool::Entry e;
     mpc_hip_handle* h;
-    Lease() : h(pool().acquire()) {}
-    ~Lease() { pool().release(h); }
+    Lease() : e(pool().acquire()), h(e.h) {}
+    ~Lease() { pool().release(e); }
 };
 
 /* what the between-levels callback needs: the clock, the deadline, and the cancellation test */
@@ -98,6 +130,16 @@ double poll(void* p)
 }
 
 }  // namespace
+
+/* Another boat (the reference's TODO at VehicleState.h:84): every later Controller::mpc solve of this process runs with
+ * this hull.  Declared in controller_mpc_hip.h; the host-side VehicleState of this repository follows through
+ * mpc_amd/host/hull.h (mpc_host_set_hull sets both), a maintainer's own VehicleState.h through its constants. */
+extern "C" void mpc_controller_set_hull(const mpc_model* hull)
+{
+    mpc_model m;
+    if (hull) m = *hull; else mpc_hip_default_model(&m);
+    pool().setHull(m);
+}
 
 Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referenceTrajectory, double endTime,
                                      long trajectoryNumber)

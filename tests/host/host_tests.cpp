@@ -13,9 +13,13 @@
 #include <cstring>
 #include <thread>
 
+#include <atomic>
+#include <vector>
+
 #include "NodeStub.h"
+#include "hull.h"
 #include "../../oracle/mpc_oracle.h"
-#include "../../include/mpc_hip.h"
+#include "mpc_hip.h"
 
 static int g_failed = 0, g_checks = 0;
 #define CHECK(cond)                                                                                  \
@@ -109,6 +113,65 @@ static void currentEstimatorTests()
         ce.enable(); ce.resetEstimate();
         CHECK(ce.getCurrent(v.state).first == 0.0);
     }
+}
+
+/* Another boat (the reference's TODO, VehicleState.h:84): the host classes follow mpc_host_set_hull and stay bit-identical
+ * to the oracle under orc_set_model; the default hull comes back with NULL. */
+static const mpc_model& secondHull()
+{
+    static mpc_model m = [] { mpc_model h; mpc_hip_default_model(&h); h.max_rpm = 2800; h.idle_rpm = 200; h.max_rpm_change_rate = 700;
+                              h.prop_pitch = 18; h.mass = 3200; h.max_power = 12000; h.max_speed = 3.4; h.rudder_distance = 2.5;
+                              h.max_rudder_angle = 0.45; return h; }();
+    return m;
+}
+static orc_model toOrc(const mpc_model& h)
+{
+    return orc_model{h.idle_rpm, h.max_rpm, h.max_rpm_change_rate, h.prop_ratio, h.prop_pitch, h.max_rudder_angle, h.rudder_coefficient,
+                     h.rudder_distance, h.mass, h.max_power, h.max_speed};
+}
+
+static void secondHullOnTheHost()
+{
+    const orc_model om = toOrc(secondHull());
+    mpc_host_set_hull(&secondHull());
+    orc_set_model(&om);
+    bool differs = false;
+    for (int i = 0; i < 100; i++) {
+        const double rud = -1.1 + 0.023 * i, thr = -0.05 + 0.011 * i, t = 0.05 * (i % 40) + 0.02;
+        State s(2.0 * i, -1.5 * i, std::fmod(0.41 * i, 2 * M_PI), 0.03 * i, 20.0 + i);
+        VehicleState a = VehicleState(s).simulate(rud, thr, t, std::make_pair(0.02 * (i % 7), -0.01 * (i % 4)));
+        orc_vehicle ov = orc_vehicle_from_state(to_orc(s));
+        orc_vehicle b = orc_simulate(&ov, rud, thr, t, 0.02 * (i % 7), -0.01 * (i % 4));
+        CHECK(a.state.x() == b.s.x && a.state.y() == b.s.y && a.state.heading() == b.s.heading);
+        CHECK(a.state.speed() == b.s.speed && a.rpm == b.rpm && a.state.time() == b.s.time);
+        CHECK(a.courseMadeGood == b.cmg && a.speedOverGround == b.sog);
+        CHECK(VehicleState(s).rpm == ov.rpm);
+        orc_set_model(nullptr);
+        orc_vehicle dv = orc_vehicle_from_state(to_orc(s));
+        orc_vehicle d = orc_simulate(&dv, rud, thr, t, 0.02 * (i % 7), -0.01 * (i % 4));
+        differs |= d.s.x != b.s.x;
+        orc_set_model(&om);
+    }
+    CHECK(differs);                                       /* the second hull is really another boat */
+    {   /* CurrentEstimator replays with the hull in force */
+        CurrentEstimator ce;
+        VehicleState v(State(5, 5, 1.0, 2.0, 100.0));
+        orc_history_entry hist[64]; int n = 0;
+        for (int i = 0; i < 50; i++) {
+            ce.updateEstimate(v.state, -0.3, 0.6);
+            if (i >= 20) { hist[n].s = to_orc(v.state); hist[n].rudder = -0.3; hist[n].throttle = 0.6; n++; }
+            v = v.simulate(-0.3, 0.6, 0.1, std::make_pair(-0.2, 0.25));
+        }
+        auto c = ce.getCurrent(v.state);
+        double ox, oy;
+        orc_current_estimate(hist, n, 1, to_orc(v.state), &ox, &oy);
+        CHECK(c.first == ox && c.second == oy);
+    }
+    mpc_host_set_hull(nullptr);
+    orc_set_model(nullptr);
+    VehicleState v(State(10, -5, 1.25, 2.0, 100));         /* the default hull is back: the reference-run golden vector */
+    VehicleState r = v.simulate(0.5, 0.75, 1.0, std::make_pair(0.3, -0.2));
+    CHECK(r.state.x() == 12.361913597579116 && r.rpm == 2400 && r.speedOverGround == 2.4573982973073774);
 }
 
 static DubinsPlan semicircle(double* endTime = nullptr, double truncateSeconds = -1)
@@ -209,6 +272,95 @@ static void mpcErrorBehaviour()
     CHECK(threw);
 }
 
+/* Controller::mpc with another hull on both sides of the C-ABI (mpc_host_set_hull) against the oracle's tree search with
+ * the same hull (orc_set_model); then the reference's hull again. */
+static void mpcWithSecondHull()
+{
+    const orc_model om = toOrc(secondHull());
+    mpc_host_set_hull(&secondHull());
+    orc_set_model(&om);
+    mpcMatchesOracle(4.5, 0.2, -0.1);
+    mpcMatchesOracle(6.5, -0.1, 0.15);
+    mpc_host_set_hull(nullptr);
+    orc_set_model(nullptr);
+    mpcMatchesOracle(4.5, 0.2, -0.1);
+}
+
+static bool sameMpcState(const Controller::MpcState& a, const Controller::MpcState& b)
+{
+    return a.state.state.x() == b.state.state.x() && a.state.state.y() == b.state.state.y() &&
+           a.state.state.heading() == b.state.state.heading() && a.state.state.speed() == b.state.state.speed() &&
+           a.state.state.time() == b.state.state.time() && a.state.rpm == b.state.rpm &&
+           a.state.courseMadeGood == b.state.courseMadeGood && a.state.speedOverGround == b.state.speedOverGround &&
+           a.LastRudder == b.LastRudder && a.LastThrottle == b.LastThrottle && a.Score == b.Score;
+}
+
+/* SURVEY.md section 7 hard part 7: the service thread starts a solve (controller.cpp:267) while the old MPC thread is
+ * still inside its last one (:385; the threads meet at :295) -- up to two Controller::mpc calls overlap on one
+ * Controller.  Two threads, one Controller, the same trajectory number, a frozen clock; one solves a short plan (the
+ * strict model expands the tree), the other a long one (the streamlined model does): every one of the overlapping
+ * solves must return what the same solve returns alone, bit for bit. */
+static void twoOverlappingSolves(double shortPlan, double longPlan, int solves)
+{
+    NodeStub stub(true, 1000.0);
+    Controller c(&stub);
+    c.updateConfig(0.0625, 0.125, 1, 20, 5, 20, true, 5);
+    c.updateDisturbanceEstimate(0.2, -0.1);
+    c.setTrajectoryNumber(5);
+    const DubinsPlan planA = semicircle(nullptr, shortPlan), planB = semicircle(nullptr, longPlan);
+    const State start(0, 0, 0, 2.5, 4);
+    const Controller::MpcState aloneA = c.mpc(start, planA, 1e18, 5), aloneB = c.mpc(start, planB, 1e18, 5);
+    CHECK(aloneA.state.state.time() > 4.9 && aloneB.state.state.time() > 4.9);
+    std::atomic<int> go(0), wrongA(0), wrongB(0), threw(0);
+    auto worker = [&](const DubinsPlan& plan, const Controller::MpcState& want, std::atomic<int>& wrong) {
+        go++;
+        while (go.load() < 2) std::this_thread::yield();       /* both threads start solving together */
+        for (int i = 0; i < solves; i++) {
+            try { if (!sameMpcState(c.mpc(start, plan, 1e18, 5), want)) wrong++; }
+            catch (const std::exception& e) { threw++; std::fprintf(stderr, "overlapping solve threw: %s\n", e.what()); }
+        }
+    };
+    std::thread ta(worker, std::cref(planA), std::cref(aloneA), std::ref(wrongA));
+    std::thread tb(worker, std::cref(planB), std::cref(aloneB), std::ref(wrongB));
+    ta.join(); tb.join();
+    CHECK(wrongA.load() == 0); CHECK(wrongB.load() == 0); CHECK(threw.load() == 0);
+    CHECK(stub.displayedNow() == 2 + 2 * solves);              /* every solve displayed its trajectory (controller.cpp:197-200) */
+}
+
+/* The stale-number path while a solve is running: one thread keeps solving under trajectory number 5, the other moves
+ * the controller on to number 6 (updateReferenceTrajectory does, controller.cpp:258).  A solve that began before the change
+ * either completes with the right answer or is cancelled between levels; every solve after it returns the default
+ * MpcState -- State() has time -1 -- as controller.cpp:30-32 and :83-86 do. */
+static void staleNumberWhileSolving(double planSeconds)
+{
+    NodeStub stub(true, 1000.0);
+    Controller c(&stub);
+    c.updateConfig(0.0625, 0.125, 1, 20, 5, 20, true, 5);
+    c.setTrajectoryNumber(5);
+    const DubinsPlan plan = semicircle(nullptr, planSeconds);
+    const State start(0, 0, 0, 2.5, 4);
+    const Controller::MpcState alone = c.mpc(start, plan, 1e18, 5);
+    std::atomic<int> solved(0), moved(0), afterMove(0), wrong(0), staleAfter(0);
+    std::thread solver([&] {
+        for (int i = 0; i < 400; i++) {
+            const bool movedBefore = moved.load() != 0;
+            const Controller::MpcState got = c.mpc(start, plan, 1e18, 5);
+            const bool empty = got.state.state.time() == -1;
+            if (!empty && !sameMpcState(got, alone)) wrong++;
+            if (movedBefore) { afterMove++; if (empty) staleAfter++; }
+            solved++;
+        }
+    });
+    while (solved.load() < 20) std::this_thread::yield();
+    c.setTrajectoryNumber(6);
+    moved = 1;
+    solver.join();
+    CHECK(wrong.load() == 0);
+    CHECK(afterMove.load() > 0 && staleAfter.load() == afterMove.load());
+    CHECK(c.mpc(start, plan, 1e18, 5).state.state.time() == -1);
+    CHECK(sameMpcState(c.mpc(start, plan, 1e18, 6), alone));   /* the new number solves as before */
+}
+
 /* The achievability block of updateReferenceTrajectory (controller.cpp:312-335) and getStateAfterCurrentControl's
  * discarded simulate (:345-359), pinned against the oracle with a frozen clock:
  *   score <= threshold  -> the state ON the plan at the predicted state's time, m_Achievable = true
@@ -299,23 +451,33 @@ static void updateReferenceTrajectoryTest()
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
-    if (!gpu) {
+    const bool threads = argc > 1 && std::strcmp(argv[1], "threads") == 0;
+    if (!gpu && !threads) {
         headingTowardsTest();
         vehicleStateMatchesOracleBitForBit();
         estimateTests();
         currentEstimatorTests();
+        secondHullOnTheHost();
         planAndCompareStates();
+    } else if (threads) {
+        /* the two-thread cases alone (the ThreadSanitizer build of this runner runs them against the test double of
+         * the C-ABI, tests/host/tsan_double_mpc_hip.cpp: no device) */
+        twoOverlappingSolves(4.5, 7.5, 40);
+        staleNumberWhileSolving(5.5);
     } else {
         mpcMatchesOracle(3.5, 0.2, -0.1);
         mpcMatchesOracle(4.5, 0.2, -0.1);
         mpcMatchesOracle(5.5, 0.2, -0.1);
         mpcMatchesOracle(6.5, 0.0, 0.0);
         mpcErrorBehaviour();
+        mpcWithSecondHull();
+        twoOverlappingSolves(4.5, 7.5, 100);          /* depth 3: the strict model expands; depth 6: the streamlined one */
+        staleNumberWhileSolving(7.5);
         achievabilityBlock(20.0);                 /* cfg default (mpc.cfg:17-18): achievable -> the state on the plan */
         achievabilityBlock(1e-9);                 /* not achievable -> predicted state, m_Achievable false */
         achievabilityBlock(0.0);                  /* threshold 0: always the prediction, never reported as failure */
         updateReferenceTrajectoryTest();
     }
-    std::printf("%s: %d checks, %d failed\n", gpu ? "gpu" : "cpu", g_checks, g_failed);
+    std::printf("%s: %d checks, %d failed\n", argc > 1 ? argv[1] : "cpu", g_checks, g_failed);
     return g_failed ? 1 : 0;
 }
