@@ -128,6 +128,12 @@ def main():
                          "solves per launch (a 65,536-candidate set is one wave per SIMD: the second wave comes from the next solve)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the combine step: nccl = RCCL over xGMI (the measured path); gloo = the "
+                         "exchange staged through pinned host memory (rehearsals: RCCL refuses two ranks on one device)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="every rank uses cuda:0 (with --backend gloo: the N-rank pipeline end to end on a 1-GPU box; the ranks "
+                         "time-share the GPU, so the line is a functional rehearsal, not a measurement)")
     args = ap.parse_args()
 
     # --gpus N without a launcher: start the N ranks ourselves, BEFORE anything in this process touches the GPU (a
@@ -162,19 +168,28 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the measured path")
+    if args.same_device:
+        if world > 1 and args.backend == "nccl":
+            raise SystemExit("--same-device with several ranks needs --backend gloo (RCCL refuses two ranks on one device)")
+        local = 0
     torch.cuda.set_device(local)
     if world > 1 or args.force_collective:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    # how many ranks RCCL really connected: an all-reduce of ones over the communicator the combine step uses
-    rccl_ranks = None
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    # how many ranks the backend really connected: an all-reduce of ones over the communicator the combine step uses
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"       # where the tensors of the bench's own small collectives live
+    rccl_ranks = ranks = None
     if dist.is_initialized():
-        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        ones = torch.ones(1, dtype=torch.int64, device=coll_dev)
         dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
-        assert rccl_ranks == world, (rccl_ranks, world)
+        ranks = int(ones.item())
+        assert ranks == world, (ranks, world)
+        rccl_ranks = ranks if args.backend == "nccl" else None
 
     prec = M.PREC_FAST if args.precision == "fast" else M.PREC_F64
     stream = torch.cuda.Stream()
@@ -264,7 +279,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if world > 1:
-                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             return dt, comb
@@ -330,7 +345,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "timed_region_ms": elapsed * 1e3,
             "timed_regions": {"count": len(regions), "reported": "median", "min_ms": min(regions) * 1e3, "max_ms": max(regions) * 1e3,
                               "note": "each region is exactly `steps` steps between barrier + synchronize"},
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": rccl_ranks, "ranks": ranks, "backend": (args.backend if dist.is_initialized() else None),
+            "rehearsal": ("%d ranks time-share cuda:0 and exchange through host memory (gloo): the N-rank pipeline end to end on "
+                          "one GPU -- a functional rehearsal, NOT a measurement" % world) if (args.same_device and world > 1) else None,
             "higher_is_better": True,
             "scaling": "strong" if args.workload == "config5" else "weak",     # config 5 splits a fixed 4096-vessel fleet
             "vs_baseline": None,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPC_HIP_ABI_VERSION 1
+#define MPC_HIP_ABI_VERSION 2          /* 2: mpc_result.libm_tie, mpc_tree_level.libm_tie, precision/selection arguments of combine_shards_exact */
 #define MPC_MAX_DEPTH 64        /* search depth D in 1-s scoring levels (BASELINE configs use 20 and 30)   */
 #define MPC_MAX_SUBSTEPS 64     /* Euler substeps per level S (11 reference-native, 20 for 0.05 s steps)    */
 
@@ -63,6 +63,15 @@ typedef enum {
 } mpc_precision;
 
 #define MPC_REFINE_REL 1.0e-6
+/* "Same chosen control" has one limit that no implementation can remove: two candidates whose reference-arithmetic scores
+ * differ by an ulp or two are ordered by the last bits of sin/cos/atan2/exp, i.e. by WHICH libm evaluated them (the
+ * reference's own choice between them depends on its glibc build: glibc picks FMA or non-FMA variants by CPU).  The
+ * device's functions are < 1 ulp but not glibc's bits.  Results therefore carry a flag, libm_tie: set when the strict
+ * (reference-arithmetic) score of the runner-up lies within MPC_TIE_ULPS units in the last place of the winner's -- the
+ * choice is then auditable as libm-dependent instead of silently different.  (Exactly equal scores also set it; those
+ * resolve by ordinal, as the reference's first-strict-minimum rule does, and are NOT libm-dependent when the candidates
+ * are mirror images of each other.) */
+#define MPC_TIE_ULPS 2
 
 typedef enum {
     MPC_SELECT_LAST_STEP = 0,       /* the reference's rule: compare the LAST level's score, controller.cpp:155-166 */
@@ -107,7 +116,8 @@ typedef struct {
     uint64_t evaluated;             /* candidates (leaves) scored                                            */
     uint64_t rollout_steps;         /* estimate() calls this solve performed (the unit of the steps/s metric) */
     uint32_t refined;               /* candidates re-evaluated by the strict kernel                          */
-    uint32_t reserved;
+    uint32_t libm_tie;              /* 1: the strict runner-up is within MPC_TIE_ULPS ulps of the winner (see above); tree
+                                     * search: of the deepest completed level.  Within one GPU's candidates / leaves.   */
     float    kernel_ms;             /* HIP-event time of the dominant rollout kernel(s) of this call         */
     float    total_ms;              /* HIP-event time from first launch to last kernel end                   */
     mpc_level_state trajectory[MPC_MAX_DEPTH + 1];   /* [levels+1]; [0] = start (controller.cpp:185-188)      */
@@ -300,12 +310,15 @@ int         mpc_hip_set_winner_record_sink(mpc_hip_handle *h, uint64_t *d_dst, u
  * shard, all ranks decide alike, and nothing but the gathered buffer and the resident problems is read -- and
  * d_out[row] = (score bits, global ordinal = gathered ordinal + shard * ordinal_stride) of the lexicographic minimum:
  * the reference's first strict minimum (controller.cpp:158-166) across GPUs, because the true minimum always lies
- * inside the near set and every record outside it is larger than every strict score inside it.  Strict-mode runs
- * reduce to mpc_hip_combine_shards.  One small kernel on the handle's stream (a wave per row, a lane per shard:
+ * inside the near set and every record outside it is larger than every strict score inside it.  precision and
+ * selection are those of the runs that PRODUCED the records (they say how to read them, whatever the handle ran last):
+ * MPC_PREC_F64 records already carry the reference's arithmetic and reduce to mpc_hip_combine_shards; selection names
+ * the score a re-scored winner is compared by.  One small kernel on the handle's stream (a wave per row, a lane per shard:
  * n_shards <= 64).  h_tied_rows (optional; synchronises): rows that had a cross-shard near-tie since the handle was
  * created (d_gathered == NULL: only read it).  No counterpart in the reference. */
 int         mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
-                                         uint32_t depth, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows);
+                                         uint32_t depth, uint64_t ordinal_stride, int precision, int selection,
+                                         uint64_t *d_out, uint32_t *h_tied_rows);
 /* Streams of solves: the deferred finish.  A run is two kernels -- the rollouts with their workgroup argmins, then one
  * small workgroup per problem that reduces them, decides near-ties with the strict model and writes winners, result
  * and trajectory -- and for a 65,536-candidate solve the second one, with its dispatch boundary, is 15 % of the time.
@@ -363,6 +376,7 @@ int         mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, double 
 typedef double (*mpc_time_fn)(void *ctx);
 typedef struct {
     uint64_t n_leaves, best_leaf; double best_score, best_cumulative;
+    uint32_t libm_tie, reserved;    /* libm_tie: this level's strict runner-up is within MPC_TIE_ULPS ulps of its winner */
 } mpc_tree_level;
 int         mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels,
                                int precision, mpc_time_fn now, void *now_ctx, double end_time,

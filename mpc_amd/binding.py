@@ -65,7 +65,7 @@ class Result(C.Structure):
                 ("best_last", C.c_double), ("best_cumulative", C.c_double),
                 ("first_rudder", C.c_double), ("first_throttle", C.c_double),
                 ("evaluated", C.c_uint64), ("rollout_steps", C.c_uint64),
-                ("refined", C.c_uint32), ("reserved", C.c_uint32),
+                ("refined", C.c_uint32), ("libm_tie", C.c_uint32),
                 ("kernel_ms", C.c_float), ("total_ms", C.c_float),
                 ("trajectory", LevelState * (MAX_DEPTH + 1))]
 
@@ -93,7 +93,7 @@ class HistorySample(C.Structure):
 
 class TreeLevel(C.Structure):
     _fields_ = [("n_leaves", C.c_uint64), ("best_leaf", C.c_uint64), ("best_score", C.c_double),
-                ("best_cumulative", C.c_double)]
+                ("best_cumulative", C.c_double), ("libm_tie", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 TIME_FN = C.CFUNCTYPE(C.c_double, C.c_void_p)
@@ -140,7 +140,7 @@ def load_library(path=None):
     L.mpc_hip_device_winners.argtypes = [vp, C.POINTER(vp)]
     L.mpc_hip_copy_winners.argtypes = [vp, vp]
     L.mpc_hip_combine_shards.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp]
-    L.mpc_hip_combine_shards_exact.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64, vp, C.POINTER(C.c_uint32)]
+    L.mpc_hip_combine_shards_exact.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64, i32, i32, vp, C.POINTER(C.c_uint32)]
     L.mpc_hip_copy_winner_records.argtypes = [vp, vp, C.c_uint32]
     L.mpc_hip_set_winner_record_sink.argtypes = [vp, vp, C.c_uint32]
     L.mpc_hip_upload_problems_from_plans.argtypes = [vp, PP, C.POINTER(u64), C.POINTER(Plan), dp, C.c_uint32]
@@ -383,15 +383,17 @@ class Solver:
     def combine_shards(self, d_gathered, n_shards, n_problems, ordinal_stride, d_out):
         _check(self._L.mpc_hip_combine_shards(self._h, _ptr(d_gathered), n_shards, n_problems, ordinal_stride, _ptr(d_out)))
 
-    def combine_shards_exact(self, d_gathered, n_shards, n_rows, depth, ordinal_stride, d_out):
-        """the exact cross-shard decision on gathered winner records of winner_record_words(depth) words (mpc_hip.h)"""
+    def combine_shards_exact(self, d_gathered, n_shards, n_rows, depth, ordinal_stride, d_out, precision=PREC_FAST,
+                             selection=SELECT_LAST_STEP):
+        """the exact cross-shard decision on gathered winner records of winner_record_words(depth) words (mpc_hip.h);
+        precision / selection: those of the runs that produced the records"""
         _check(self._L.mpc_hip_combine_shards_exact(self._h, _ptr(d_gathered), n_shards, n_rows, int(depth), ordinal_stride,
-                                                    _ptr(d_out), None))
+                                                    int(precision), int(selection), _ptr(d_out), None))
 
     def tied_rows(self):
         """rows that had a cross-shard near-tie in this handle's combine_shards_exact calls so far; synchronises"""
         n = C.c_uint32(0)
-        _check(self._L.mpc_hip_combine_shards_exact(self._h, None, 0, 0, 0, 0, None, C.byref(n)))
+        _check(self._L.mpc_hip_combine_shards_exact(self._h, None, 0, 0, 0, 0, 0, 0, None, C.byref(n)))
         return n.value
 
     def copy_winner_records(self, d_dst, depth):

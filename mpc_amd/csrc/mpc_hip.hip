@@ -149,7 +149,7 @@ extern "C" void mpc_hip_destroy(mpc_hip_handle *h)
     (void)hipFree(h->d_probs); (void)hipHostFree(h->h_probs);
     (void)hipFree(h->d_results); (void)hipHostFree(h->h_results); (void)hipFree(h->d_results_alt); (void)hipFree(h->d_winners_alt);
     (void)hipFree(h->d_winners); (void)hipFree(h->d_list_count); (void)hipFree(h->d_pcnt);
-    (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord);
+    (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord); (void)hipFree(h->d_pkey2);
     for (WorkMem &w : h->wm) { (void)hipFree(w.d_keys); (void)hipFree(w.d_snap); (void)hipFree(w.d_pkey); (void)hipFree(w.d_pord); (void)hipFree(w.d_pcnt); }
     (void)hipFree(h->d_controls); (void)hipFree(h->d_models); (void)hipFree(h->d_tied_rows); (void)hipHostFree(h->h_pair); (void)hipFree(h->d_plans); (void)hipFree(h->d_hist);
     (void)hipFree(h->d_hist_ring); (void)hipFree(h->d_hist_state); (void)hipFree(h->d_hist_io); (void)hipHostFree(h->h_hist_io);
@@ -182,7 +182,7 @@ int mpc_ensure_problem_capacity(mpc_hip_handle *h, uint32_t n)
     HIP_TRY(hipHostMalloc(&h->h_probs, sizeof(DevProblem) * n));
     HIP_TRY(hipMalloc(&h->d_results, sizeof(DevResult) * n));
     HIP_TRY(hipHostMalloc(&h->h_results, sizeof(DevResult) * n));
-    HIP_TRY(hipMalloc(&h->d_winners, sizeof(uint64_t) * (2 * (size_t)n + 4)));   /* the tree search uses 4 words */
+    HIP_TRY(hipMalloc(&h->d_winners, sizeof(uint64_t) * (2 * (size_t)n + 8)));   /* the tree search uses 6 words */
     HIP_TRY(hipMalloc(&h->d_list_count, sizeof(uint32_t) * n));
     HIP_TRY(hipMalloc(&h->d_results_alt, sizeof(DevResult) * n));
     HIP_TRY(hipMalloc(&h->d_winners_alt, sizeof(uint64_t) * 2 * (size_t)n));
@@ -194,9 +194,10 @@ int mpc_ensure_partials(mpc_hip_handle *h, size_t n)
 {
     if (n <= h->cap_partials) return MPC_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord); (void)hipFree(h->d_pcnt);
-    h->d_pkey = h->d_pord = nullptr; h->d_pcnt = nullptr; h->cap_partials = 0;
+    (void)hipFree(h->d_pkey); (void)hipFree(h->d_pord); (void)hipFree(h->d_pcnt); (void)hipFree(h->d_pkey2);
+    h->d_pkey = h->d_pord = h->d_pkey2 = nullptr; h->d_pcnt = nullptr; h->cap_partials = 0;
     HIP_TRY(hipMalloc(&h->d_pkey, sizeof(uint64_t) * n));
+    HIP_TRY(hipMalloc(&h->d_pkey2, sizeof(uint64_t) * n));
     HIP_TRY(hipMalloc(&h->d_pord, sizeof(uint64_t) * n));
     HIP_TRY(hipMalloc(&h->d_pcnt, sizeof(uint32_t) * n));
     h->cap_partials = n;
@@ -729,6 +730,7 @@ static void fill_result(const mpc_hip_handle *h, uint32_t p, const DevResult &R,
     out->evaluated = h->last_count;
     out->rollout_steps = h->last_count * (uint64_t)D * (uint64_t)h->nsub[p];
     out->refined = R.refined;
+    out->libm_tie = R.tie;
     out->kernel_ms = k1_ms; out->total_ms = total_ms;
     memcpy(out->trajectory, R.traj, sizeof(mpc_level_state) * (size_t)(D + 1));
     out->status = MPC_OK;
@@ -828,7 +830,8 @@ extern "C" int mpc_hip_combine_shards(mpc_hip_handle *h, const uint64_t *d_gathe
 }
 
 extern "C" int mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_gathered, uint32_t n_shards, uint32_t n_rows,
-                                            uint32_t depth, uint64_t ordinal_stride, uint64_t *d_out, uint32_t *h_tied_rows)
+                                            uint32_t depth, uint64_t ordinal_stride, int precision, int selection,
+                                            uint64_t *d_out, uint32_t *h_tied_rows)
 {
     if (h && !d_gathered && h_tied_rows) {           /* read the counter only */
         if (int s = mpc_use_device(h)) return s;
@@ -841,8 +844,10 @@ extern "C" int mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d
     }
     if (!h || !d_gathered || !d_out || n_shards == 0 || n_rows == 0) { mpc_set_err("combine_shards_exact: NULL or empty argument"); return MPC_ERR_INVALID; }
     if (n_shards > 64) { mpc_set_err("combine_shards_exact: more than 64 shards"); return MPC_ERR_TOO_LARGE; }
+    if (precision != MPC_PREC_FAST && precision != MPC_PREC_F64) { mpc_set_err("combine_shards_exact: unknown precision"); return MPC_ERR_INVALID; }
+    if (selection != MPC_SELECT_LAST_STEP && selection != MPC_SELECT_CUMULATIVE) { mpc_set_err("combine_shards_exact: unknown selection"); return MPC_ERR_INVALID; }
     if (depth < 1 || depth > MPC_MAX_DEPTH) { mpc_set_err("winner record depth out of range [1, MPC_MAX_DEPTH]"); return MPC_ERR_INVALID; }
-    if (h->n_probs == 0 || !h->ran) { mpc_set_err("combine_shards_exact: nothing has run on the resident problems"); return MPC_ERR_INVALID; }
+    if (h->n_probs == 0) { mpc_set_err("combine_shards_exact: no resident problems (the re-scoring reads them)"); return MPC_ERR_INVALID; }
     if (n_rows % h->n_probs) { mpc_set_err("combine_shards_exact: n_rows is not a multiple of the resident problems"); return MPC_ERR_INVALID; }
     for (uint32_t p = 0; p < h->n_probs; p++)
         if ((uint32_t)h->depth[p] > depth) { mpc_set_err("combine_shards_exact: a resident problem is deeper than the records"); return MPC_ERR_INVALID; }
@@ -851,9 +856,11 @@ extern "C" int mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d
         HIP_TRY(hipMalloc(&h->d_tied_rows, sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(h->d_tied_rows, 0, sizeof(uint32_t), h->stream));
     }
-    /* only fast-mode winners need re-scoring: strict-mode records already carry the reference's arithmetic */
-    const double rel = h->last_precision == MPC_PREC_FAST ? MPC_REFINE_REL : -1.0;
-    hipLaunchKernelGGL(combine_exact_kernel, dim3(n_rows), dim3(64), 0, h->stream, h->d_probs, h->n_probs, h->last_selection, d_gathered,
+    /* only fast-mode winners need re-scoring: strict-mode records already carry the reference's arithmetic.  The
+     * records' precision and selection are the CALLER'S to say (a batch is combined long after the handle's last run,
+     * which may have been of another kind) */
+    const double rel = precision == MPC_PREC_FAST ? MPC_REFINE_REL : -1.0;
+    hipLaunchKernelGGL(combine_exact_kernel, dim3(n_rows), dim3(64), 0, h->stream, h->d_probs, h->n_probs, selection, d_gathered,
                        n_shards, n_rows, (uint32_t)MPC_WINNER_RECORD_WORDS(depth), ordinal_stride, rel, d_out, h->d_tied_rows);
     HIP_TRY(hipGetLastError());
     if (h_tied_rows) {                       /* optional read-back (synchronises): rows with a cross-shard near-tie so far */

@@ -36,6 +36,7 @@ struct DevResult {
     uint64_t key_bits, ordinal;
     double best_last, best_cum;
     uint32_t refined, overflow;
+    uint32_t tie, pad;              /* tie: the strict runner-up lies within MPC_TIE_ULPS ulps of the winner (mpc_result.libm_tie) */
     mpc_level_state traj[MPC_MAX_DEPTH + 1];
 };
 
@@ -148,6 +149,7 @@ struct mpc_hip_handle {
     uint32_t winner_sink_words = 2;                             /* 2, or 2 + 2 * depth (records with controls) */
     uint32_t *d_list_count = nullptr;                           /* per-problem scratch word (tree trace cursor) */
     uint64_t *d_pkey = nullptr, *d_pord = nullptr;              /* K1 workgroup triples */
+    uint64_t *d_pkey2 = nullptr;                                /* tree search: every expansion workgroup's runner-up key (libm_tie) */
     uint32_t *d_pcnt = nullptr;
     size_t cap_partials = 0;
     WorkMem wm[4];                                              /* keys, snapshots (and the triples of all but wm[0]); level 1 uses two, level 2 four */
@@ -226,6 +228,10 @@ __device__ inline void wave_argmin(uint64_t &k, uint64_t &o)
         lex_min(k, o, k2, o2);
     }
 }
+
+/* The strict scores a and b (key bits of non-negative doubles, a <= b) lie within MPC_TIE_ULPS units in the last place:
+ * for such doubles the difference of the bit patterns IS the distance in ulps. */
+__device__ inline bool keys_tie(uint64_t a, uint64_t b) { return a < KEY_INF && b < KEY_INF && b - a <= (uint64_t)MPC_TIE_ULPS; }
 
 /* block argmin: every thread of the block must call; result valid in thread 0 (all of wave 0).
  * red must hold 2 * (blockDim.x / 64) uint64 of LDS. */

@@ -338,7 +338,19 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
     /* no finite score anywhere: nothing is ever below the reference's initial minScore = DBL_MAX
      * (controller.cpp:81,160), so nothing is selected */
     uint64_t win = k < KEY_INF ? o : ~0ull;
-    uint32_t n = 0, overflow = 0;
+    uint32_t n = 0, overflow = 0, tie = 0;
+    /* strict runs: is there a second candidate within MPC_TIE_ULPS ulps of the winner (mpc_result.libm_tie)?  In another
+     * workgroup its triple shows it; inside the winner's own, K1's near count does (strict runs count against +2 ulps). */
+    if (!fast && k < KEY_INF) {
+        int t = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < FIN_U; u++) {
+            const uint32_t j = u * blockDim.x + threadIdx.x;
+            if (j < nblk) t |= keys_tie(k, kk[u]) && (oo[u] != o || cc[u] > 1);
+        }
+        for (uint32_t j = FIN_U * blockDim.x + threadIdx.x; j < nblk; j += blockDim.x) t |= keys_tie(k, pk[j]) && (po[j] != o || pc[j] > 1);
+        tie = __syncthreads_or(t) != 0;
+    }
 
     /* 2. fast mode: the candidates within refine_rel of the minimum */
     if (fast && k < KEY_INF) {
@@ -369,17 +381,27 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
         if (n > LIST_CAP) { overflow = 1; n = LIST_CAP; }
         /* 3. more than one: the strict model decides, lowest ordinal among equal scores */
         if (n > 1) {
-            uint64_t k2 = ~0ull, o2 = ~0ull;
+            uint64_t k2 = ~0ull, o2 = ~0ull, second = ~0ull;       /* this thread's best and the key of its next best */
             for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
                 const uint64_t ord = s_list[e];
                 double last, cum;
                 eval_strict<SEEDED>(P, cpL, subL, c, ord, ord - first, last, cum, nullptr, snap_none());
-                lex_min(k2, o2, key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last), ord);
+                const uint64_t ke = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
+                if (ke < k2 || (ke == k2 && ord < o2)) { second = k2; k2 = ke; o2 = ord; }
+                else if (ke < second) second = ke;
             }
+            const uint64_t my_k = k2, my_o = o2;
             block_argmin(k2, o2, red);
-            if (threadIdx.x == 0) s_win[1] = o2;
+            if (threadIdx.x == 0) { s_win[0] = k2; s_win[1] = o2; }
             __syncthreads();
             win = s_win[1];
+            /* the strict runner-up: every thread offers its best, the winner's holder its next best */
+            uint64_t ru = (my_o == win) ? second : my_k, zero = 0;
+            const uint64_t wk = s_win[0];
+            block_argmin(ru, zero, red);
+            if (threadIdx.x == 0) s_win[0] = ru;
+            __syncthreads();
+            tie = keys_tie(wk, s_win[0]);
         } else if (n == 1) {
             win = s_list[0];
         }
@@ -390,7 +412,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
     const bool keep_fast = fast && n <= 1;
     if (win == ~0ull) {
         if (threadIdx.x == 0) {
-            R.key_bits = KEY_INF; R.ordinal = win; R.best_last = 0; R.best_cum = 0; R.refined = 0; R.overflow = overflow;
+            R.key_bits = KEY_INF; R.ordinal = win; R.best_last = 0; R.best_cum = 0; R.refined = 0; R.overflow = overflow; R.tie = 0;
             winners[2 * p] = KEY_INF; winners[2 * p + 1] = win;
             if (sink) { sink[(size_t)p * sw] = KEY_INF; sink[(size_t)p * sw + 1] = win; }
         }
@@ -459,7 +481,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
             const uint64_t kb = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
             R.traj[0] = mpc_level_state{P.sx, P.sy, P.sh, P.sv, P.srpm, 0.0, 0.0, P.last_r, P.last_t, 0.0};
             R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
-            R.refined = 0; R.overflow = overflow;
+            R.refined = 0; R.overflow = overflow; R.tie = tie;
             winners[2 * p] = kb; winners[2 * p + 1] = win;
             if (sink) { sink[(size_t)p * sw] = kb; sink[(size_t)p * sw + 1] = win; }
         }
@@ -471,7 +493,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
         else eval_strict<SEEDED>(P, cpL, subL, c, win, win - first, last, cum, R.traj, snap_none());
         const uint64_t kb = key_of(selection == MPC_SELECT_CUMULATIVE ? cum : last);
         R.key_bits = kb; R.ordinal = win; R.best_last = last; R.best_cum = cum;
-        R.refined = n > 1 ? n : 0; R.overflow = overflow;
+        R.refined = n > 1 ? n : 0; R.overflow = overflow; R.tie = tie;
         winners[2 * p] = kb; winners[2 * p + 1] = win;
         if (sink) {
             sink[(size_t)p * sw] = kb; sink[(size_t)p * sw + 1] = win;
@@ -591,7 +613,11 @@ __device__ __forceinline__ void rollout_body(const DevProblem *__restrict__ prob
     if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
     __syncthreads();
     const double m = __longlong_as_double((long long)red[8]);
-    const bool near = (i < count) && (mykey <= mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws));
+    /* strict runs have no refine window; they count the candidates within MPC_TIE_ULPS ulps of the workgroup's minimum
+     * instead, from which K2 sets mpc_result.libm_tie (an infinite minimum: +2 is a NaN pattern, nothing compares below it) */
+    const double near_limit = PREC == MPC_PREC_F64 ? __longlong_as_double((long long)(red[8] + MPC_TIE_ULPS))
+                                                   : mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws);
+    const bool near = (i < count) && (mykey <= near_limit);
     const uint32_t wave_n = (uint32_t)__popcll(__ballot(near));
     if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);
     __syncthreads();
@@ -769,7 +795,7 @@ __global__ __launch_bounds__(64) void rollout_one_kernel(const DevProblem *__res
                                                 r, t, cum);
         }
     }
-    R.key_bits = key_of(last); R.ordinal = 0; R.best_last = last; R.best_cum = cum; R.refined = 0; R.overflow = 0;
+    R.key_bits = key_of(last); R.ordinal = 0; R.best_last = last; R.best_cum = cum; R.refined = 0; R.overflow = 0; R.tie = 0;
 }
 
 #endif

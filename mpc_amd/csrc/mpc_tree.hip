@@ -79,7 +79,7 @@ static LevelPtrs ptrs(const TreeLevelBuf &b)
  * cmg = cos(heading), v, rpm, sog = the last substep's v*dt -- the FastVeh of mpc_model.h in the same arrays. */
 /* meta (optional; the blind shallow levels, below): also the root's child count and offsets, so that level 1 can be
  * expanded without a scan launch: meta[l * TREE_META + 0] = nodes of level l */
-#define TREE_META 8              /* uint64 per level: nodes, winner key, winner ordinal, cum bits, last bits, overflow, clock, - */
+#define TREE_META 8              /* uint64 per level: nodes, winner key, winner ordinal, cum bits, last bits, overflow, clock, libm tie */
 __global__ void root_kernel(const DevProblem *__restrict__ probs, LevelPtrs L, int fast, uint32_t *__restrict__ bpar,
                             uint64_t *__restrict__ meta)
 {
@@ -253,10 +253,10 @@ template <bool STORE>
 __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                      const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
                                                      uint32_t tpb, uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
-                                                     const uint64_t *__restrict__ meta_parent)
+                                                     uint64_t *__restrict__ pkey2, const uint64_t *__restrict__ meta_parent)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
-    __shared__ uint64_t red[8];
+    __shared__ uint64_t red[10];
     __shared__ uint32_t win[2][PARENT_WINDOW];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
@@ -264,13 +264,13 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     const uint32_t n_tiles = (n_child + 255) / 256;
     const uint32_t tile0 = blockIdx.x * tpb;
     if (tile0 >= n_tiles) {                                          /* uniform: a workgroup beyond the level */
-        if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; }
+        if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; pkey2[blockIdx.x] = ~0ull; }
         return;
     }
     uint32_t par0 = bpar[tile0];                                     /* the parent of the tile's first child (scan_apply_kernel) */
     if (threadIdx.x < PARENT_WINDOW) win[0][threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
     stage_problem(P, cpL, subL);                                     /* ends with a barrier */
-    uint64_t k = ~0ull, o = ~0ull;
+    uint64_t k = ~0ull, o = ~0ull, second = ~0ull;                   /* this lane's best child and the key of its next best */
     for (uint32_t i = 0; i < tpb && tile0 + i < n_tiles; i++) {
         const uint32_t tile = tile0 + i;
         const bool more = i + 1 < tpb && tile + 1 < n_tiles;
@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
             const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
             const Child ch = make_child(P, cpL, subL, A, par, c - first, level);
             if (STORE) store_child(B, c, ch);
-            lex_min(k, o, key_of(ch.score), (uint64_t)c);
+            const uint64_t kc = key_of(ch.score);
+            if (kc < k) { second = k; k = kc; o = c; }                /* (a lane's children come in ascending order: ties keep the first) */
+            else if (kc < second) second = kc;
         }
         if (more) {
             if (threadIdx.x < PARENT_WINDOW) win[(i + 1) & 1][threadIdx.x] = off_next;
@@ -293,8 +295,25 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
             __syncthreads();
         }
     }
+    const uint64_t my_k = k, my_o = o;
     block_argmin(k, o, red);
-    if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; }
+    if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; red[8] = o; }
+    __syncthreads();
+    /* the workgroup's runner-up key (mpc_tree_level.libm_tie): every lane offers its best, the winner's lane its next best */
+    uint64_t ru = (my_o == red[8]) ? second : my_k, zero = 0;
+    block_argmin(ru, zero, red);
+    if (threadIdx.x == 0) pkey2[blockIdx.x] = ru;
+}
+
+/* the level's runner-up key from the workgroups' (key, ordinal, runner-up key): a workgroup other than the winner's offers
+ * its best, the winner's its runner-up; every thread of the block must call, valid in thread 0 */
+__device__ inline uint64_t level_runner_up(const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
+                                           const uint64_t *__restrict__ pkey2, uint32_t nblk, uint64_t winner, uint64_t *red)
+{
+    uint64_t ru = ~0ull, zero = 0;
+    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) ru = min(ru, pord[j] == winner ? pkey2[j] : pkey[j]);
+    block_argmin(ru, zero, red);
+    return ru;
 }
 
 /* the winner of a level that was expanded without stores: evaluated once more (same code, same bits) into slot 0 of
@@ -474,7 +493,7 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     __syncthreads();
     k = s_win[0]; o = s_win[1];
     if (k >= KEY_INF) {                                      /* no finite score: nothing selected */
-        if (threadIdx.x == 0) { out[0] = KEY_INF; out[1] = ~0ull; out[2] = KEY_INF; out[3] = KEY_INF; out[4] = 0; }
+        if (threadIdx.x == 0) { out[0] = KEY_INF; out[1] = ~0ull; out[2] = KEY_INF; out[3] = KEY_INF; out[4] = 0; out[5] = 0; }
         return;
     }
     const double m = __longlong_as_double((long long)k);
@@ -509,7 +528,7 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     uint32_t n = s_n;
     if (n > LIST_CAP) { overflow = 1; n = LIST_CAP; }
     /* the strict model along each listed leaf's path decides, lowest ordinal among equal scores */
-    uint64_t k2 = ~0ull, o2 = ~0ull;
+    uint64_t k2 = ~0ull, o2 = ~0ull, second = ~0ull;
     double my_last = 0, my_cum = 0;
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         PathCtl pc;
@@ -517,13 +536,20 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
         double last, cum;
         strict_path(P, cpL, subL, pc, L, last, cum, nullptr);
         const uint64_t ke = key_of(last);
-        if (ke < k2 || (ke == k2 && s_list[e] < o2)) { k2 = ke; o2 = s_list[e]; my_last = last; my_cum = cum; }
+        if (ke < k2 || (ke == k2 && s_list[e] < o2)) { second = k2; k2 = ke; o2 = s_list[e]; my_last = last; my_cum = cum; }
+        else if (ke < second) second = ke;
     }
     const uint64_t mine_k = k2, mine_o = o2;
     block_argmin(k2, o2, red);
     if (threadIdx.x == 0) { s_win[0] = k2; s_win[1] = o2; }
     __syncthreads();
-    if (mine_k == s_win[0] && mine_o == s_win[1] && mine_o != ~0ull) {      /* exactly one lane holds the winner */
+    const uint64_t wk = s_win[0], wo = s_win[1];
+    /* the strict runner-up (mpc_tree_level.libm_tie): a leaf outside the near-tie list is > MPC_REFINE_REL away, never
+     * within an ulp or two */
+    uint64_t ru = (mine_o == wo) ? second : mine_k, zero = 0;
+    block_argmin(ru, zero, red);
+    if (threadIdx.x == 0) out[5] = keys_tie(wk, ru);
+    if (mine_k == wk && mine_o == wo && mine_o != ~0ull) {      /* exactly one lane holds the winner */
         out[0] = mine_k; out[1] = mine_o;
         out[2] = (uint64_t)__double_as_longlong(my_cum); out[3] = (uint64_t)__double_as_longlong(my_last);
         out[4] = overflow;
@@ -553,7 +579,8 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void tree_post_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
                                                         int L, int stored, double refine_rel, uint32_t tpb,
                                                         const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
-                                                        const uint32_t *__restrict__ pcnt, uint64_t *__restrict__ out,
+                                                        const uint32_t *__restrict__ pcnt, const uint64_t *__restrict__ pkey2,
+                                                        uint64_t *__restrict__ out,
                                                         uint64_t *__restrict__ meta, int do_scan, uint32_t *__restrict__ bpar)
 {
     __shared__ __attribute__((aligned(16))) TreeFinishLds S;
@@ -569,7 +596,11 @@ __global__ __launch_bounds__(256) void tree_post_kernel(const DevProblem *__rest
         uint64_t k = ~0ull, o = ~0ull;
         for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
         block_argmin(k, o, S.red);
+        if (threadIdx.x == 0) { S.s_win[0] = k; S.s_win[1] = o; }
+        __syncthreads();
+        const uint64_t ru = level_runner_up(pkey, pord, pkey2, nblk, S.s_win[1], S.red);
         if (threadIdx.x == 0) {
+            out[5] = keys_tie(k, ru);
             uint64_t cum = KEY_INF, last = KEY_INF;
             if (o != ~0ull) {
                 uint32_t at = (uint32_t)o;
@@ -588,7 +619,7 @@ __global__ __launch_bounds__(256) void tree_post_kernel(const DevProblem *__rest
     if (threadIdx.x == 0) {
         uint64_t *m = meta + (L + 1) * TREE_META;
         m[1] = out[0]; m[2] = out[1]; m[3] = out[2]; m[4] = out[3]; m[5] = FAST ? out[4] : 0;
-        m[6] = (uint64_t)wall_clock64();
+        m[6] = (uint64_t)wall_clock64(); m[7] = out[5];
     }
     if (!do_scan) return;
     /* the new level as parents: children per node (controller.cpp:121-146) and their exclusive scan, one workgroup */
@@ -629,14 +660,18 @@ __global__ __launch_bounds__(64) void path_trace_kernel(const DevProblem *__rest
 /* stage 1: (key, ordinal) of the level; stage 2 (a second launch, after leaf_record_kernel where the level was not
  * stored): the winner's cumulative and last-step score from its record (slot `o`, or slot 0 of a one-node buffer) */
 __global__ __launch_bounds__(256) void level_reduce_kernel(const uint64_t *__restrict__ pkey,
-                                                           const uint64_t *__restrict__ pord, uint32_t nblk,
-                                                           uint64_t *__restrict__ out)
+                                                           const uint64_t *__restrict__ pord, const uint64_t *__restrict__ pkey2,
+                                                           uint32_t nblk, uint64_t *__restrict__ out)
 {
     __shared__ uint64_t red[8];
+    __shared__ uint64_t s_o;
     uint64_t k = ~0ull, o = ~0ull;
     for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
     block_argmin(k, o, red);
-    if (threadIdx.x == 0) { out[0] = k; out[1] = o; }
+    if (threadIdx.x == 0) { out[0] = k; out[1] = o; s_o = o; }
+    __syncthreads();
+    const uint64_t ru = level_runner_up(pkey, pord, pkey2, nblk, s_o, red);
+    if (threadIdx.x == 0) out[5] = keys_tie(k, ru);
 }
 
 __global__ void level_scores_kernel(LevelPtrs B, int stored, uint64_t *__restrict__ out)
@@ -756,9 +791,11 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     int completed = 0;
     uint64_t best_leaf = 0, steps = 0, evaluated = 0;
     bool leaf_stored = true, overflow = false, stop = false;
-    auto record_level = [&](int it, uint64_t nchild, const uint64_t *w, bool stored) {
+    uint32_t last_tie = 0;
+    auto record_level = [&](int it, uint64_t nchild, const uint64_t *w, bool stored, uint64_t tie) {
         completed = it + 1;
         best_leaf = w[1];
+        last_tie = tie != 0;
         leaf_stored = stored;
         evaluated += nchild;
         steps += nchild * (uint64_t)h_problem->n_substeps;
@@ -767,6 +804,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             h_level_best[it].best_leaf = w[1];
             memcpy(&h_level_best[it].best_score, &w[3], sizeof(double));
             memcpy(&h_level_best[it].best_cumulative, &w[2], sizeof(double));
+            h_level_best[it].libm_tie = tie != 0; h_level_best[it].reserved = 0;
         }
     };
     /* every shard has expanded the split level in full; from there on this one keeps a contiguous slice of its nodes
@@ -788,7 +826,10 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         const int lim = n_shards > 1 ? std::min(max_levels, split_level) : max_levels;
         uint64_t bound = 1;
         static const bool sync_levels = getenv("MPC_HIP_TREE_SYNC_LEVELS") != nullptr;     /* diagnostic: every level the long way */
-        while (!sync_levels && blind < lim && bound * 30 <= BLIND_MAX_NODES) { bound *= 30; blind++; }
+        /* a caller's node budget bounds memory and work: only levels whose 30^l bound fits it are expanded blind (their
+         * buffers and grids are sized for the bound); the levels beyond go the synchronised way, which sizes by the real
+         * counts and stops at the budget before allocating */
+        while (!sync_levels && blind < lim && bound * 30 <= BLIND_MAX_NODES && (own_cap || bound * 30 <= max_nodes)) { bound *= 30; blind++; }
     }
     if (now && now(now_ctx) >= end_time) blind = 0;                       /* the loop below breaks at once */
     if (!h->d_tree_meta) {
@@ -834,15 +875,15 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
                 else hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
                                         (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp);
                 hipLaunchKernelGGL(tree_post_kernel<true>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
-                                   (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_winners, h->d_tree_meta,
+                                   (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_pkey2, h->d_winners, h->d_tree_meta,
                                    (int)(stored && it + 1 < blind), h->d_bpar);
             } else {
                 if (stored) hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                               (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, mp);
+                                               (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp);
                 else hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                        (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, mp);
+                                        (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp);
                 hipLaunchKernelGGL(tree_post_kernel<false>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
-                                   0.0, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_winners, h->d_tree_meta,
+                                   0.0, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_pkey2, h->d_winners, h->d_tree_meta,
                                    (int)(stored && it + 1 < blind), h->d_bpar);
             }
             pb = cb;
@@ -864,7 +905,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             if (fast && m[5]) { overflow = true; break; }                 /* > LIST_CAP tied leaves: the strict expansion decides */
             if (now && t_after >= end_time && t_after - (double)(clk_ref - m[6]) * 1.0e-8 >= end_time) { stop = true; break; }
             h->tree[it + 1].n = stored ? nchild : 1;
-            record_level(it, nchild, m + 1, stored);
+            record_level(it, nchild, m + 1, stored, m[7]);
             if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
             if (!stored) { stop = true; break; }
         }
@@ -931,21 +972,21 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, (const uint64_t *)nullptr);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr);
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, (const uint64_t *)nullptr);
-            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, nblk, h->d_winners);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr);
+            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
             if (!stored)
                 hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
             hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * (fast ? 5 : 4), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * 6, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (fast && h->h_pair[4]) { overflow = true; break; }            /* > LIST_CAP tied leaves: the strict expansion decides */
         if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
-        record_level(it, nchild, h->h_pair, stored);
+        record_level(it, nchild, h->h_pair, stored, h->h_pair[5]);
         if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
         if (!stored) break;                                              /* nothing to expand the next level from */
     }
@@ -988,6 +1029,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     h_result->best_last = R.best_last; h_result->best_cumulative = R.best_cum;
     h_result->first_rudder = R.traj[1].rudder; h_result->first_throttle = R.traj[1].throttle;
     h_result->evaluated = evaluated; h_result->rollout_steps = steps;
+    h_result->libm_tie = last_tie;
     h_result->kernel_ms = k1; h_result->total_ms = total;
     memcpy(h_result->trajectory, R.traj, sizeof(mpc_level_state) * (size_t)(completed + 1));
     h_result->status = MPC_OK;

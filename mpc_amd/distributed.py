@@ -88,15 +88,19 @@ class ShardCombiner:
                      GPUs, from ONE exchange
         exact=False  16-byte records, mpc_hip_combine_shards on the fast keys (two shards whose winners lie within the
                      fast model's ~1e-7 error may then resolve differently from the reference)
-    No host synchronisation anywhere.  ordinal_stride: what separates the shards' local ordinals (0 when the shards
+    No host synchronisation anywhere over RCCL.  Over a backend that moves host memory only (gloo: the CPU tests, and the
+    rehearsal of N ranks on ONE GPU, which RCCL refuses) the batch is staged through pinned host buffers -- device ->
+    host copy on the stream, ONE stream synchronisation per batch, the gather, host -> device copy before the combine
+    kernel -- the solver must then run on torch's current stream.  ordinal_stride: what separates the shards' local ordinals (0 when the shards
     were run with their first_ordinal).  depth: levels per record, >= the deepest resident problem.  The exact decision
     reads the resident problems: flush() before they change.
     flush() returns the combined (score bits, global ordinal) of the LAST solve; `results` holds the last batch.
     """
 
     def __init__(self, solver, n_problems, ordinal_stride=0, group=None, batch=16, slots=3, always=False, exact=True,
-                 depth=None):
+                 depth=None, precision=0, selection=0):
         self.solver, self.P, self.stride, self.group = solver, int(n_problems), int(ordinal_stride), group
+        self.precision, self.selection = int(precision), int(selection)     # of the runs whose records are combined
         self.B = int(batch)
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -116,6 +120,12 @@ class ShardCombiner:
             w.view(-1, self.W)[:, 1] = -1
         torch.cuda.synchronize(dev)          # the solver's stream may not be torch's
         self.gathered = [z(self.B * row * self.world) if self.collective else None for _ in range(slots)]
+        # a backend without device collectives (gloo): the exchange goes through pinned host memory
+        self.host_staged = self.collective and dist.get_backend(group) != "nccl"
+        if self.host_staged:
+            hz = lambda n: torch.zeros(n, dtype=torch.int64).pin_memory()
+            self.win_h = [hz(self.B * row) for _ in range(slots)]
+            self.gathered_h = [hz(self.B * row * self.world) for _ in range(slots)]
         self.results = z(self.B * 2 * self.P)
         self.work = [None] * slots
         self.pending = []                    # slots whose batch is not combined yet, oldest first
@@ -126,8 +136,11 @@ class ShardCombiner:
         if self.work[r] is not None:
             self.work[r].wait()              # the current stream waits for the collective (no host sync)
             self.work[r] = None
+            if self.host_staged:
+                self.gathered[r].copy_(self.gathered_h[r], non_blocking=True)
         if self.exact:
-            self.solver.combine_shards_exact(self.gathered[r], self.world, rows, self.depth, self.stride, self.results)
+            self.solver.combine_shards_exact(self.gathered[r], self.world, rows, self.depth, self.stride, self.results,
+                                             self.precision, self.selection)
         else:
             src = self.gathered[r] if self.collective else self.win[r]
             self.solver.combine_shards(src, self.world if self.collective else 1, rows, self.stride, self.results)
@@ -140,7 +153,15 @@ class ShardCombiner:
     def _close_batch(self):
         r = self.slot
         self.solver.flush()                  # a deferred finish (mpc_hip_set_pipeline) deposits the batch's last row now
-        if self.collective:
+        if self.fill < self.B:               # a partial batch: the rows behind it still hold an OLDER batch's records in a
+            tail = self.win[r].view(self.B * self.P, self.W)[self.fill * self.P:]      # reused slot -- "nothing selected" again,
+            tail[:, 0] = 0x7FF0000000000000                                            # so that they are neither re-scored nor
+            tail[:, 1] = -1                                                            # counted as near-tie rows
+        if self.host_staged:
+            self.win_h[r].copy_(self.win[r], non_blocking=True)
+            torch.cuda.current_stream(self.win[r].device).synchronize()    # the host collective reads the pinned copy
+            self.work[r] = dist.all_gather_into_tensor(self.gathered_h[r], self.win_h[r], group=self.group, async_op=True)
+        elif self.collective:
             self.work[r] = dist.all_gather_into_tensor(self.gathered[r], self.win[r], group=self.group, async_op=True)
         self.pending.append(r)
         self.last = (r, self.fill - 1)
@@ -191,7 +212,7 @@ class ShardCombiner:
         return o[:, 0], o[:, 1]
 
 
-def combine_shards_exact(solver, records, depth, ordinal_stride=0):
+def combine_shards_exact(solver, records, depth, ordinal_stride=0, precision=0, selection=0):
     """The exact cross-shard decision with every shard in THIS process (rehearsal of N GPUs on one): records int64
     [n_shards, rows, winner_record_words(depth)] on the device (copy_winner_records of each shard's run, shard-local
     ordinals as the runs reported them; torch.stack in place of the all-gather) -> int64 [rows, 2] = (strict-decided
@@ -200,12 +221,12 @@ def combine_shards_exact(solver, records, depth, ordinal_stride=0):
     g = records.contiguous()
     torch.cuda.synchronize()
     out = torch.zeros((rows, 2), dtype=torch.int64, device=g.device)
-    solver.combine_shards_exact(g, n_shards, rows, depth, ordinal_stride, out)
+    solver.combine_shards_exact(g, n_shards, rows, depth, ordinal_stride, out, precision, selection)
     solver.synchronize()
     return out
 
 
-def combine_winners_exact_device(solver, depth, ordinal_stride=0, group=None):
+def combine_winners_exact_device(solver, depth, ordinal_stride=0, group=None, precision=0, selection=0):
     """One solve, every rank its own GPU: the winner records of the solver's last run -> ONE all-gather ->
     mpc_hip_combine_shards_exact, all stream-ordered on the device (the solver must run on torch's current stream).
     -> int64 [P, 2] (score bits, global ordinal), identical on every rank."""
@@ -215,9 +236,15 @@ def combine_winners_exact_device(solver, depth, ordinal_stride=0, group=None):
     mine = torch.empty(P * W, dtype=torch.int64, device=dev)
     solver.copy_winner_records(mine, depth)
     gathered = torch.empty(world * P * W, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(gathered, mine, group=group)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+    else:                                    # host collectives only (gloo): through host memory, one synchronisation
+        mine_h = mine.cpu()
+        gathered_h = torch.empty(world * P * W, dtype=torch.int64)
+        dist.all_gather_into_tensor(gathered_h, mine_h, group=group)
+        gathered.copy_(gathered_h)
     out = torch.empty((P, 2), dtype=torch.int64, device=dev)
-    solver.combine_shards_exact(gathered, world, P, depth, ordinal_stride, out)
+    solver.combine_shards_exact(gathered, world, P, depth, ordinal_stride, out, precision, selection)
     return out
 
 

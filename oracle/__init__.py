@@ -13,10 +13,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmpc_oracle.so")
 
 
+def _up_to_date():
+    """libmpc_oracle.so exists and is newer than its sources: no build step, and -- what matters on the GPU box -- no
+    child process (a process that has initialised the GPU must not fork + exec: the two-rank worker of
+    tests/test_gpu_two_ranks.py died in subprocess.Popen there)"""
+    try:
+        built = os.path.getmtime(_LIB_PATH)
+        return all(os.path.getmtime(os.path.join(_HERE, f)) <= built for f in ("mpc_oracle.c", "mpc_oracle.h", "Makefile", os.path.join("..", "include", "mpc_candidates.h")))
+    except OSError:
+        return False
+
+
 def build(force=False):
     if force and os.path.exists(_LIB_PATH):
         os.remove(_LIB_PATH)
-    subprocess.check_call(["make", "-s", "-C", _HERE, "libmpc_oracle.so"])   # no-op when up to date
+    if not _up_to_date():
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libmpc_oracle.so"])
     return _LIB_PATH
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(M.EXPORTED_SYMBOLS) == declared          # the Python binding covers the whole header
-    assert lib.mpc_hip_abi_version() == 1
+    assert lib.mpc_hip_abi_version() == 2
 
 
 def test_struct_layout_matches_the_header(tmp_path):

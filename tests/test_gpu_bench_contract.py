@@ -68,3 +68,20 @@ def test_two_kernel_form_and_rccl_rehearsal_choose_the_same_control():
 def test_other_workloads_run(workload):
     d = _bench("--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert d["value"] > 1e11 and workload[-1] in d["config"]["workload"].split(":")[0]
+
+
+def test_two_ranks_on_one_gpu_over_gloo_rehearsal():
+    """`bench.py --gpus 2 --backend gloo --same-device`: the N-rank bench path (self-launch, barriers, max over ranks,
+    ShardCombiner's batched exchange and exact combine) end to end on a 1-GPU box.  The ranks time-share cuda:0, so the
+    line is a rehearsal, and says so; what is asserted is the plumbing and the choice."""
+    a = _bench("--steps", "20", "--warmup", "4", "--no-cpu-baseline", "--repeats", "5")
+    d = _bench("--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "20", "--warmup", "4", "--repeats", "5",
+               "--combine-batch", "8")
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["rccl_ranks"] is None
+    assert d["rehearsal"] and "NOT a measurement" in d["rehearsal"]
+    assert d["scaling"] == "weak" and d["config"]["candidates_per_gpu"] == 65536
+    assert abs(d["value"] - 2 * 65536 * 400 * 20 / (d["timed_region_ms"] * 1e-3)) <= 1e-6 * d["value"]
+    # rank 0's shard is the one-GPU run's set; the combined winner is the better of the two shards'
+    assert d["chosen"]["global_ordinal_after_combine"] is not None
+    assert d["chosen"]["ordinal"] == a["chosen"]["ordinal"]
+    assert d["chosen"]["cross_shard_near_tie_rows"] == 0
