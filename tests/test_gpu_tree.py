@@ -54,6 +54,8 @@ def _check(solver, p, max_levels):
     assert (fres.best_ordinal, fres.best_last, fres.best_cumulative) == (res.best_ordinal, res.best_last, res.best_cumulative)
     for a, b in zip(flevels[:max_levels], levels[:max_levels]):
         assert (a.n_leaves, a.best_leaf, a.best_score, a.best_cumulative) == (b.n_leaves, b.best_leaf, b.best_score, b.best_cumulative)
+        assert a.libm_tie == b.libm_tie
+    assert fres.libm_tie == res.libm_tie
     return res
 
 
@@ -339,3 +341,93 @@ def test_depth_8_as_the_8_shards_of_a_node(solver):
             rs.append(lr); ts.append(lt)
         s = O.rollout(cfg, veh, cps, depth, sub, rs, ts)
         assert s[depth].score - s[depth - 1].score >= res.best_last * (1 - 1e-10)
+
+
+def _leaf_controls(p, depth):
+    """every leaf of the depth-`depth` tree in DFS order (throttle outer, rudder inner: controller.cpp:174-182) as control
+    sequences [depth][n_leaves]"""
+    paths = [([], [], p.last_rudder, p.last_throttle)]
+    for _ in range(depth):
+        nxt = []
+        for rs, ts, lr, lt in paths:
+            rud, thr = _control_sets(p, lr, lt)
+            for tt in thr:
+                for rr in rud:
+                    nxt.append((rs + [rr], ts + [tt], rr, tt))
+        paths = nxt
+    return (np.array([q[0] for q in paths], dtype=np.float64).T.copy(), np.array([q[1] for q in paths], dtype=np.float64).T.copy())
+
+
+@pytest.mark.parametrize("which", ["semicircle", "straight", "straight_with_current", "speed_only", "random"])
+def test_libm_tie_flag_is_the_two_ulp_test_on_the_strict_scores(solver, which):
+    """mpc_tree_level.libm_tie / mpc_result.libm_tie (mpc_hip.h): set exactly when a level's strict runner-up lies within
+    MPC_TIE_ULPS = 2 ulps of its winner.  The expectation comes from the device's own strict scores of EVERY leaf: the
+    tree's leaves, enumerated on the host in DFS order, evaluated as an explicit candidate set in MPC_PREC_F64."""
+    import torch
+    depth = 3
+    if which == "semicircle":
+        p, _ = _semicircle(4.5)
+    elif which == "straight":
+        p, _ = W.config1_problem(depth=depth)
+    elif which == "straight_with_current":
+        p, _ = W.config1_problem(depth=depth)
+        p.current_x, p.current_y = 0.15, -0.1
+    elif which == "speed_only":
+        # only the speed term is weighted and there is no current: speed over ground does not depend on the heading but
+        # for its rounding, so leaves that differ in their rudders alone score within an ulp or two of each other
+        p, _ = W.config1_problem(depth=depth)
+        p.w_distance, p.w_heading, p.w_speed = 0.0, 0.0, 5.0
+    else:
+        rng = np.random.RandomState(77)
+        plan = W.chain([(W.RSL, (0.4, 3.5, 0.7)), (W.LSL, (0.0, 10.0, 0.0))], 9.0, 2.2, (5.0, -3.0, 1.0), 10.0)
+        x, y, heading, _ = plan.sample(10.0)
+        p = M.make_problem((x + 1.0, y - 0.5, heading + 0.2, 1.7), plan.checkpoints(10.0, depth), M.substep_schedule(1.0),
+                           last=(0.1875, 0.625), current=(0.2, 0.1), weights=tuple(float(v) for v in rng.uniform(0.5, 25.0, size=3)))
+    strict, sl = solver.solve_tree(p, depth, precision=M.PREC_F64)
+    fast, fl = solver.solve_tree(p, depth, precision=M.PREC_FAST)
+    seen = []
+    for l in range(depth):
+        rud, thr = _leaf_controls(p, l + 1)
+        n = rud.shape[1]
+        assert n == sl[l].n_leaves
+        q = M.make_problem((p.start_x, p.start_y, p.start_heading, p.start_speed),
+                           [(p.checkpoints[i].x, p.checkpoints[i].y, p.checkpoints[i].heading, p.checkpoints[i].speed) for i in range(l + 1)],
+                           [p.substeps[i] for i in range(p.n_substeps)], last=(p.last_rudder, p.last_throttle),
+                           current=(p.current_x, p.current_y), weights=(p.w_distance, p.w_heading, p.w_speed))
+        last = torch.empty(n, dtype=torch.float64, device="cuda")
+        res = solver.eval_candidates(q, torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous(),
+                                     torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous(), n, M.PREC_F64,
+                                     M.SELECT_LAST_STEP, last, None)
+        bits = np.sort(last.cpu().numpy().view(np.int64))
+        assert bits[0] == int(np.float64(sl[l].best_score).view(np.int64)) and res.best_ordinal == sl[l].best_leaf
+        want = int(bits[1] - bits[0] <= 2)
+        assert sl[l].libm_tie == want and fl[l].libm_tie == want, (which, l, int(bits[1] - bits[0]))
+        assert res.libm_tie == want                                # the candidate-set path reports the same flag
+        seen.append(want)
+    assert strict.libm_tie == fast.libm_tie == seen[-1]
+    print(which, "libm_tie per level:", seen)
+    if which == "speed_only":
+        assert any(seen)          # the positive case is really exercised (observed: [1, 0, 1])
+
+
+def test_libm_tie_of_a_candidate_set_with_a_duplicated_winner(solver):
+    """a candidate set in which the winner occurs twice: libm_tie in both precisions (equal scores: 0 ulps apart), the
+    lower ordinal wins; without the duplicate the flag follows the two-ulp test on the strict costs"""
+    import torch
+    p = W.config2_problem(depth=8)
+    n = 5000
+    rud, thr = W.seeded_controls(W.SEED, 0, n, 8, p.last_rudder, p.last_throttle)
+    d_r = torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous()
+    d_t = torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous()
+    last = torch.empty(n, dtype=torch.float64, device="cuda")
+    base = solver.eval_candidates(p, d_r, d_t, n, M.PREC_F64, M.SELECT_LAST_STEP, last, None)
+    bits = np.sort(last.cpu().numpy().view(np.int64))
+    assert base.libm_tie == int(bits[1] - bits[0] <= 2)
+    assert solver.eval_candidates(p, d_r, d_t, n, M.PREC_FAST).libm_tie == base.libm_tie
+    w = int(base.best_ordinal)
+    for other in (w + 1 if w + 1 < n else w - 1, (w + 2500) % n):          # in the winner's own workgroup, and in another
+        r2, t2 = d_r.clone(), d_t.clone()
+        r2[:, other] = d_r[:, w]; t2[:, other] = d_t[:, w]
+        for prec in (M.PREC_F64, M.PREC_FAST):
+            res = solver.eval_candidates(p, r2, t2, n, prec)
+            assert res.libm_tie == 1 and res.best_ordinal == min(w, other), (other, prec)
