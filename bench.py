@@ -32,18 +32,22 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak = half the 157.3 TFLO
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(problem, seed, want_ordinal):
+def cpu_baseline(problem, seeds, want_ordinals):
     """The reference-equivalent CPU loop (oracle/, a port of controller.cpp:149-166 + VehicleState.h) timed on
-    ONE host thread -- the reference solve is single-threaded -- on the same candidate set."""
+    ONE host thread -- the reference solve is single-threaded -- on the same candidate sets: the sets the timed stream
+    rotates through, one after the other (each checked against the GPU's choice for THAT set), until ~10 s are covered."""
     import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_args
     cfg, veh, cps, sub = oracle_args(problem)
-    reps, t_total, best = 0, 0.0, None
-    while t_total < 10.0 and reps < 8:
+    reps, t_total, same = 0, 0.0, []
+    while (t_total < 10.0 and reps < 8) or reps < len(seeds):
+        seed, want = seeds[reps % len(seeds)], want_ordinals[reps % len(seeds)]
         t0 = time.perf_counter()
         _, _, best = O.eval_seeded(cfg, veh, cps, problem.depth, sub, seed, 0, 1, N_CAND)
         t_total += time.perf_counter() - t0
+        if reps < len(seeds):
+            same.append(bool(best.best_index == want))
         reps += 1
     steps = reps * N_CAND * problem.depth * problem.n_substeps
     # additionally (SURVEY.md 8d): the same loop on all the host threads this job may use, each on its own slice of
@@ -52,19 +56,97 @@ def cpu_baseline(problem, seed, want_ordinal):
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     per = N_CAND // threads
     def slice_(k):                     # ctypes releases the GIL inside the C call
-        return O.eval_seeded(cfg, veh, cps, problem.depth, sub, seed, k * per, 1, per)[2]
+        return O.eval_seeded(cfg, veh, cps, problem.depth, sub, seeds[0], k * per, 1, per)[2]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(slice_, range(threads)))
     t_all = time.perf_counter() - t0
     return {
         "value": steps / t_total, "unit": "steps/s", "cores": 1, "kind": "port",
-        "sample": "%d x the full config-2 set (65536 candidates x 400 steps), %.1f s" % (reps, t_total),
-        "same_choice_as_gpu": bool(best.best_index == want_ordinal),
+        "sample": "%d x a full config-2 set (65536 candidates x 400 steps; the %d sets of the timed stream in turn), %.1f s" % (reps, len(seeds), t_total),
+        "same_choice_as_gpu": all(same), "same_choice_per_set": same,
         "host_cpus": os.cpu_count(),
         "all_threads": {"value": threads * per * problem.depth * problem.n_substeps / t_all, "unit": "steps/s",
                         "cores": threads, "note": "not the reference's behaviour (its solve is single-threaded)"},
     }
+
+
+def cpu_baseline_tree(problem, depth):
+    """The oracle's restatement of the reference's own search (Controller::mpc's iterative-deepening DFS,
+    controller.cpp:80-189) on one host thread, frozen clock: wall time of the whole deepening loop up to `depth` and the
+    control it chooses.  Part of the cpu_baseline leg (the only place bench.py touches the oracle)."""
+    import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_args
+    cfg, veh, cps, sub = oracle_args(problem)
+    start = O.State(problem.start_x, problem.start_y, problem.start_heading, problem.start_speed, 0.0)
+    t0 = time.perf_counter()
+    it, traj, olev, nodes = O.mpc_tree(cfg, start, cps, depth, -1)
+    dt = time.perf_counter() - t0
+    return {"ms": dt * 1e3, "levels": int(it), "first_control": [traj[1].last_rudder, traj[1].last_throttle],
+            "leaves": int(olev[it - 1].n_leaves), "simulate_calls": int(nodes)}
+
+
+def tree_block(M, W, device, with_cpu):
+    """The PRODUCTION path in the bench line: the reference-native limited-branching tree search exactly as the drop-in
+    runs it (mpc_hip_solve_tree through the C-ABI, one synchronous solve at a time, problem upload and result copy
+    included), on the reference's own end-to-end scenario (LRL semicircle, test_controller.cpp:449-467) and on BASELINE
+    config 1's straight line: p50 wall per depth for both expansions, the deepest level completed inside the reference's
+    0.1-s planning budget (controller.h:153), and beside them the oracle's single-thread time and choice."""
+    solver = M.Solver(device)
+    solver.set_timing(0)
+    out = {"note": "p50 wall ms of one synchronous mpc_hip_solve_tree call (host -> C-ABI -> result filled); strict = the reference's "
+                   "arithmetic expands the tree, fast = the streamlined model expands and the strict one decides; cpu = the oracle's DFS "
+                   "restatement on one host thread (the whole deepening loop to that depth)",
+           "budget_s": 0.1, "scenarios": {}}
+    scenarios = {"lrl_semicircle": lambda d: W.semicircle_problem(d + 1.5)[0],
+                 "config1_straight_line": lambda d: W.config1_problem(depth=d)[0]}
+    for name, make in scenarios.items():
+        rows = {}
+        for depth in (3, 4, 5, 7):
+            p = make(depth)
+            assert p.depth == depth, (name, depth, p.depth)
+            row = {}
+            chosen = {}
+            for label, prec in (("strict", M.PREC_F64), ("fast", M.PREC_FAST)):
+                reps = 40 if depth <= 5 else 7
+                solver.solve_tree(p, depth, precision=prec)                 # warm: buffers grown, code objects loaded
+                lat = []
+                for _ in range(reps):
+                    a = time.perf_counter()
+                    res, levels = solver.solve_tree(p, depth, precision=prec)
+                    lat.append((time.perf_counter() - a) * 1e3)
+                row[label + "_p50_ms"] = float(np.median(lat))
+                chosen[label] = (res.first_rudder, res.first_throttle, int(res.best_ordinal), int(res.levels), int(res.libm_tie))
+                row["leaves"] = int(levels[depth - 1].n_leaves)
+                row["simulate_calls"] = int(res.evaluated)
+            row["first_control"] = list(chosen["strict"][:2])
+            row["libm_tie"] = bool(chosen["strict"][4])
+            row["strict_and_fast_agree"] = chosen["strict"] == chosen["fast"]
+            if with_cpu and depth <= 5:                                    # depth 7 is ~150 s on the CPU
+                c = cpu_baseline_tree(p, depth)
+                row["cpu_ms"] = c["ms"]
+                row["cpu_simulate_calls"] = c["simulate_calls"]
+                row["same_first_control"] = c["first_control"] == row["first_control"]
+            else:
+                row["cpu_ms"], row["same_first_control"] = None, None
+            rows[str(depth)] = row
+        # the deadline as the vessel has it: a real clock, 0.1 s, a plan long enough for depth 8
+        p8 = make(8)
+        deepest = {}
+        for label, prec in (("strict", M.PREC_F64), ("fast", M.PREC_FAST)):
+            got = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                res, _ = solver.solve_tree(p8, 8, precision=prec, now=time.perf_counter, end_time=t0 + 0.1)
+                got.append((int(res.levels), (time.perf_counter() - t0) * 1e3))
+            deepest[label] = {"levels": min(g[0] for g in got), "wall_ms": float(np.median([g[1] for g in got]))}
+        cpu_deepest = None
+        if with_cpu:                                                       # the deepest loop the oracle finishes inside the budget
+            cpu_deepest = max([int(d) for d, r in rows.items() if r["cpu_ms"] is not None and r["cpu_ms"] <= 100.0] or [0])
+        out["scenarios"][name] = {"depth": rows, "deepest_level_inside_budget": deepest, "cpu_deepest_level_inside_budget": cpu_deepest}
+    solver.close()
+    return out
 
 
 def measured_valu(k1_seconds, spl=1):
@@ -114,6 +196,10 @@ def main():
     ap.add_argument("--precision", choices=["fast", "f64"], default="fast")
     ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tree", action="store_true", help="skip the `tree` block (the reference-native search timed through the C-ABI)")
+    ap.add_argument("--sets", type=int, default=4,
+                    help="config 2: how many DISTINCT candidate sets (seeds SEED, SEED+1, ...) are resident and solved in turn, each with "
+                         "its own control arrays and cost outputs -- a stream of different solves, not one solve repeated")
     ap.add_argument("--timing-period", type=int, default=8,
                     help="HIP events ride on every n-th solve's dispatches inside the timed region (1 = every solve)")
     ap.add_argument("--combine-batch", type=int, default=64,
@@ -200,14 +286,25 @@ def main():
             depth, count, n_problems = 20, N_CAND, 1
             problem = W.config2_problem(depth)
             first = rank * count
-            # this rank's shard of the seeded set, as explicit FP32 SoA controls [depth][n] resident in HBM
-            rud, thr = W.seeded_controls(W.SEED, first, count, depth, problem.last_rudder, problem.last_throttle)
-            d_rud = torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous()
-            d_thr = torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous()
-            d_last = torch.empty(count, dtype=torch.float64, device="cuda")
-            d_cum = torch.empty(count, dtype=torch.float64, device="cuda")
+            # this rank's shard of every seeded set, as explicit FP32 SoA controls [depth][n] resident in HBM.  The stream
+            # rotates through --sets DISTINCT sets (own control arrays, own cost outputs): at pipeline level 2 the two solves
+            # of a launch are different candidate sets, as two consecutive solves of a sampling controller would be
+            n_sets = max(1, args.sets)
+            set_seeds = [W.SEED + k for k in range(n_sets)]
+            sets = []
+            for sd in set_seeds:
+                rud, thr = W.seeded_controls(sd, first, count, depth, problem.last_rudder, problem.last_throttle)
+                sets.append((torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous(),
+                             torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous(),
+                             torch.empty(count, dtype=torch.float64, device="cuda"), torch.empty(count, dtype=torch.float64, device="cuda")))
+            d_rud, d_thr, d_last, d_cum = sets[0]
             solver.upload([problem], [W.SEED])
-            launch = lambda: solver.run_candidates(d_rud, d_thr, count, prec, M.SELECT_LAST_STEP, d_last, d_cum)
+            turn = [0]
+
+            def launch():
+                r_, t_, l_, c_ = sets[turn[0] % n_sets]
+                turn[0] += 1
+                solver.run_candidates(r_, t_, count, prec, M.SELECT_LAST_STEP, l_, c_)
             offset = first
             what = ("BASELINE config 2: 65,536 seeded candidates per GPU x 20 s horizon (20 levels x 20 Euler substeps "
                     "of 0.05 s), curved Dubins reference (LSR+RSL+LRL, rho 8 m, 2.5 m/s), explicit FP32 SoA controls "
@@ -262,6 +359,7 @@ def main():
         solver.set_timing(max(1, min(args.timing_period, args.steps)))
         for _ in range(args.warmup):
             step()
+        solver.flush()                     # an odd warmup leaves no run waiting for a partner from the timed region
         solver.timing(reset=True)
 
         def timed_region():
@@ -269,6 +367,8 @@ def main():
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
+            if args.workload == "config2":
+                turn[0] = 0                                    # every region solves the same sequence of sets: 0, 1, ..., K-1 mod --sets
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 step()
@@ -313,6 +413,20 @@ def main():
             solver.set_pipeline(level)
         res = solver.fetch()[0]
         solver.set_pipeline(False)  # the latency loop is one synchronous solve at a time
+        # what the GPU chooses for EVERY set of the stream (one synchronous solve each): the CPU baseline checks each
+        set_choices = None
+        if args.workload == "config2":
+            set_choices = []
+            for r_, t_, l_, c_ in sets:
+                solver.run_candidates(r_, t_, count, prec, M.SELECT_LAST_STEP, l_, c_)
+                q = solver.fetch()[0]
+                set_choices.append({"ordinal": int(q.best_ordinal) + offset, "rudder": q.first_rudder, "throttle": q.first_throttle,
+                                    "last_score": q.best_last, "libm_tie": bool(q.libm_tie)})
+            # `chosen` below: the set the timed region's LAST solve worked on (the one a combine's last row refers to)
+            last_set = (args.steps - 1) % n_sets
+            r_, t_, l_, c_ = sets[last_set]
+            solver.run_candidates(r_, t_, count, prec, M.SELECT_LAST_STEP, l_, c_)
+            res = solver.fetch()[0]
         solver.set_timing(0)       # the latency loop below is timed by the host clock: no events on its dispatches (~5 us each)
 
         # p50 solve latency (BASELINE's second metric): host call -> result struct filled, including the problem upload,
@@ -357,6 +471,11 @@ def main():
                        "depth": depth, "substeps_per_level": nsub,
                        "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
                        "selection": "last_step", "deferred_finish": level >= 1, "pipeline_level": level, "solves_per_launch": spl,
+                       "distinct_candidate_sets": (n_sets if args.workload == "config2" else None),
+                       "stream": (("%d independent solves share each rollout launch (mpc_hip_set_pipeline level 2): a 65,536-candidate set is one "
+                                   "wave per SIMD, the second wave comes from the NEXT solve of the stream -- a different candidate set with its own "
+                                   "control arrays and outputs; `one_solve_per_launch` gives the rate without it" % spl) if spl > 1 else
+                                  "one solve per rollout launch"),
                        "parallelism": ("candidate shards; per %d solves ONE async RCCL all-gather of the winner records (score, ordinal, controls), then "
                                        "mpc_hip_combine_shards_exact: strict re-score of cross-shard near-ties from the gathered controls, "
                                        "the reference's first strict minimum across GPUs" % args.combine_batch if combine else
@@ -371,6 +490,7 @@ def main():
             "solve_gpu_ms": total_ms_sum / max(runs, 1),
             "chosen": {"ordinal": int(res.best_ordinal) + offset, "rudder": res.first_rudder,
                        "throttle": res.first_throttle, "last_score": res.best_last,
+                       "per_set": set_choices,
                        "global_ordinal_after_combine": (int(combined[1][0].item()) if combined else None),
                        "cross_shard_near_tie_rows": (combiner.tied_rows() if combiner else None)},
             "roofline": {
@@ -388,7 +508,9 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "config2":
-            line["cpu_baseline"] = cpu_baseline(problem, W.SEED, int(res.best_ordinal))
+            line["cpu_baseline"] = cpu_baseline(problem, set_seeds, [c["ordinal"] for c in set_choices])
+        if world == 1 and not args.no_tree and args.workload == "config2":
+            line["tree"] = tree_block(M, W, local, with_cpu=not args.no_cpu_baseline)
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     solver.close()

@@ -63,15 +63,18 @@ typedef enum {
 } mpc_precision;
 
 #define MPC_REFINE_REL 1.0e-6
-/* "Same chosen control" has one limit that no implementation can remove: two candidates whose reference-arithmetic scores
- * differ by an ulp or two are ordered by the last bits of sin/cos/atan2/exp, i.e. by WHICH libm evaluated them (the
- * reference's own choice between them depends on its glibc build: glibc picks FMA or non-FMA variants by CPU).  The
- * device's functions are < 1 ulp but not glibc's bits.  Results therefore carry a flag, libm_tie: set when the strict
- * (reference-arithmetic) score of the runner-up lies within MPC_TIE_ULPS units in the last place of the winner's -- the
- * choice is then auditable as libm-dependent instead of silently different.  (Exactly equal scores also set it; those
- * resolve by ordinal, as the reference's first-strict-minimum rule does, and are NOT libm-dependent when the candidates
- * are mirror images of each other.) */
-#define MPC_TIE_ULPS 2
+/* "Same chosen control" has one limit that no implementation can remove: two candidates whose reference-arithmetic
+ * scores are closer than the arithmetic is reproducible are ordered by the last bits of sin/cos/atan2/exp, i.e. by WHICH
+ * libm evaluated them (the reference's own choice between them depends on its glibc build: glibc picks FMA or non-FMA
+ * variants by CPU).  The device's functions are < 1 ulp but not glibc's bits, and an ulp of atan2 is several ulps of a
+ * score once the heading weight has multiplied it: a measured case (tools/fuzz_tree.py 2000 11, problem 326) has two
+ * leaves 3 ulps apart on the device and 1 ulp apart THE OTHER WAY ROUND under this container's glibc.  Results therefore
+ * carry a flag, libm_tie: set when the strict (reference-arithmetic) score of the runner-up lies within MPC_TIE_REL of
+ * the winner's -- relative to max(score, 1 % of the weights' sum), like every tolerance of this header; 1e-12 is the
+ * validation mode's own contract, inside which no order is promised.  A choice that differs from the reference's is then
+ * auditable as libm-dependent instead of silently different.  (Exactly equal scores also set it; those resolve by
+ * ordinal, as the reference's first-strict-minimum rule does.) */
+#define MPC_TIE_REL 1.0e-12
 
 typedef enum {
     MPC_SELECT_LAST_STEP = 0,       /* the reference's rule: compare the LAST level's score, controller.cpp:155-166 */
@@ -116,7 +119,7 @@ typedef struct {
     uint64_t evaluated;             /* candidates (leaves) scored                                            */
     uint64_t rollout_steps;         /* estimate() calls this solve performed (the unit of the steps/s metric) */
     uint32_t refined;               /* candidates re-evaluated by the strict kernel                          */
-    uint32_t libm_tie;              /* 1: the strict runner-up is within MPC_TIE_ULPS ulps of the winner (see above); tree
+    uint32_t libm_tie;              /* 1: the strict runner-up is within MPC_TIE_REL of the winner (see above); tree
                                      * search: of the deepest completed level.  Within one GPU's candidates / leaves.   */
     float    kernel_ms;             /* HIP-event time of the dominant rollout kernel(s) of this call         */
     float    total_ms;              /* HIP-event time from first launch to last kernel end                   */
@@ -376,7 +379,7 @@ int         mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, double 
 typedef double (*mpc_time_fn)(void *ctx);
 typedef struct {
     uint64_t n_leaves, best_leaf; double best_score, best_cumulative;
-    uint32_t libm_tie, reserved;    /* libm_tie: this level's strict runner-up is within MPC_TIE_ULPS ulps of its winner */
+    uint32_t libm_tie, reserved;    /* libm_tie: this level's strict runner-up is within MPC_TIE_REL of its winner */
 } mpc_tree_level;
 int         mpc_hip_solve_tree(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels,
                                int precision, mpc_time_fn now, void *now_ctx, double end_time,

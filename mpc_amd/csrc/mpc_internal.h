@@ -36,7 +36,7 @@ struct DevResult {
     uint64_t key_bits, ordinal;
     double best_last, best_cum;
     uint32_t refined, overflow;
-    uint32_t tie, pad;              /* tie: the strict runner-up lies within MPC_TIE_ULPS ulps of the winner (mpc_result.libm_tie) */
+    uint32_t tie, pad;              /* tie: the strict runner-up lies within MPC_TIE_REL of the winner (mpc_result.libm_tie) */
     mpc_level_state traj[MPC_MAX_DEPTH + 1];
 };
 
@@ -229,9 +229,13 @@ __device__ inline void wave_argmin(uint64_t &k, uint64_t &o)
     }
 }
 
-/* The strict scores a and b (key bits of non-negative doubles, a <= b) lie within MPC_TIE_ULPS units in the last place:
- * for such doubles the difference of the bit patterns IS the distance in ulps. */
-__device__ inline bool keys_tie(uint64_t a, uint64_t b) { return a < KEY_INF && b < KEY_INF && b - a <= (uint64_t)MPC_TIE_ULPS; }
+/* The strict scores with key bits a <= b lie within MPC_TIE_REL of each other (mpc_result.libm_tie): the window of
+ * mpc_refine_limit at the validation mode's own tolerance -- relative to max(score, 1 % of the weights' sum). */
+__host__ __device__ inline double mpc_tie_limit(double m, double wd, double wh, double ws) { return mpc_refine_limit(m, MPC_TIE_REL, wd, wh, ws); }
+__device__ inline bool keys_tie(uint64_t a, uint64_t b, double wd, double wh, double ws)
+{
+    return a < KEY_INF && b < KEY_INF && __longlong_as_double((long long)b) <= mpc_tie_limit(__longlong_as_double((long long)a), wd, wh, ws);
+}
 
 /* block argmin: every thread of the block must call; result valid in thread 0 (all of wave 0).
  * red must hold 2 * (blockDim.x / 64) uint64 of LDS. */

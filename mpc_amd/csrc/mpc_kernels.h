@@ -339,16 +339,16 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
      * (controller.cpp:81,160), so nothing is selected */
     uint64_t win = k < KEY_INF ? o : ~0ull;
     uint32_t n = 0, overflow = 0, tie = 0;
-    /* strict runs: is there a second candidate within MPC_TIE_ULPS ulps of the winner (mpc_result.libm_tie)?  In another
-     * workgroup its triple shows it; inside the winner's own, K1's near count does (strict runs count against +2 ulps). */
+    /* strict runs: is there a second candidate within MPC_TIE_REL of the winner (mpc_result.libm_tie)?  In another
+     * workgroup its triple shows it; inside the winner's own, K1's near count does (strict runs count against that window). */
     if (!fast && k < KEY_INF) {
         int t = 0;
 #pragma unroll
         for (uint32_t u = 0; u < FIN_U; u++) {
             const uint32_t j = u * blockDim.x + threadIdx.x;
-            if (j < nblk) t |= keys_tie(k, kk[u]) && (oo[u] != o || cc[u] > 1);
+            if (j < nblk) t |= keys_tie(k, kk[u], P.wd, P.wh, P.ws) && (oo[u] != o || cc[u] > 1);
         }
-        for (uint32_t j = FIN_U * blockDim.x + threadIdx.x; j < nblk; j += blockDim.x) t |= keys_tie(k, pk[j]) && (po[j] != o || pc[j] > 1);
+        for (uint32_t j = FIN_U * blockDim.x + threadIdx.x; j < nblk; j += blockDim.x) t |= keys_tie(k, pk[j], P.wd, P.wh, P.ws) && (po[j] != o || pc[j] > 1);
         tie = __syncthreads_or(t) != 0;
     }
 
@@ -401,7 +401,7 @@ __device__ inline void finish_body(const FinishArgs &A, uint32_t p, double *lds,
             block_argmin(ru, zero, red);
             if (threadIdx.x == 0) s_win[0] = ru;
             __syncthreads();
-            tie = keys_tie(wk, s_win[0]);
+            tie = keys_tie(wk, s_win[0], P.wd, P.wh, P.ws);
         } else if (n == 1) {
             win = s_list[0];
         }
@@ -613,10 +613,9 @@ __device__ __forceinline__ void rollout_body(const DevProblem *__restrict__ prob
     if (threadIdx.x == 0) { red[8] = k; *cnt = 0; }
     __syncthreads();
     const double m = __longlong_as_double((long long)red[8]);
-    /* strict runs have no refine window; they count the candidates within MPC_TIE_ULPS ulps of the workgroup's minimum
-     * instead, from which K2 sets mpc_result.libm_tie (an infinite minimum: +2 is a NaN pattern, nothing compares below it) */
-    const double near_limit = PREC == MPC_PREC_F64 ? __longlong_as_double((long long)(red[8] + MPC_TIE_ULPS))
-                                                   : mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws);
+    /* strict runs have no refine window; they count the candidates within MPC_TIE_REL of the workgroup's minimum instead,
+     * from which K2 sets mpc_result.libm_tie */
+    const double near_limit = mpc_refine_limit(m, PREC == MPC_PREC_F64 ? MPC_TIE_REL : refine_rel, P.wd, P.wh, P.ws);
     const bool near = (i < count) && (mykey <= near_limit);
     const uint32_t wave_n = (uint32_t)__popcll(__ballot(near));
     if ((threadIdx.x & 63) == 0 && wave_n) atomicAdd(cnt, wave_n);

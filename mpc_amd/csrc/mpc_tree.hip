@@ -548,7 +548,7 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
      * within an ulp or two */
     uint64_t ru = (mine_o == wo) ? second : mine_k, zero = 0;
     block_argmin(ru, zero, red);
-    if (threadIdx.x == 0) out[5] = keys_tie(wk, ru);
+    if (threadIdx.x == 0) out[5] = keys_tie(wk, ru, P.wd, P.wh, P.ws);
     if (mine_k == wk && mine_o == wo && mine_o != ~0ull) {      /* exactly one lane holds the winner */
         out[0] = mine_k; out[1] = mine_o;
         out[2] = (uint64_t)__double_as_longlong(my_cum); out[3] = (uint64_t)__double_as_longlong(my_last);
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void tree_post_kernel(const DevProblem *__rest
         __syncthreads();
         const uint64_t ru = level_runner_up(pkey, pord, pkey2, nblk, S.s_win[1], S.red);
         if (threadIdx.x == 0) {
-            out[5] = keys_tie(k, ru);
+            out[5] = keys_tie(k, ru, P.wd, P.wh, P.ws);
             uint64_t cum = KEY_INF, last = KEY_INF;
             if (o != ~0ull) {
                 uint32_t at = (uint32_t)o;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64) void path_trace_kernel(const DevProblem *__rest
 
 /* stage 1: (key, ordinal) of the level; stage 2 (a second launch, after leaf_record_kernel where the level was not
  * stored): the winner's cumulative and last-step score from its record (slot `o`, or slot 0 of a one-node buffer) */
-__global__ __launch_bounds__(256) void level_reduce_kernel(const uint64_t *__restrict__ pkey,
+__global__ __launch_bounds__(256) void level_reduce_kernel(const DevProblem *__restrict__ probs, const uint64_t *__restrict__ pkey,
                                                            const uint64_t *__restrict__ pord, const uint64_t *__restrict__ pkey2,
                                                            uint32_t nblk, uint64_t *__restrict__ out)
 {
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void level_reduce_kernel(const uint64_t *__res
     if (threadIdx.x == 0) { out[0] = k; out[1] = o; s_o = o; }
     __syncthreads();
     const uint64_t ru = level_runner_up(pkey, pord, pkey2, nblk, s_o, red);
-    if (threadIdx.x == 0) out[5] = keys_tie(k, ru);
+    if (threadIdx.x == 0) out[5] = keys_tie(k, ru, probs[0].wd, probs[0].wh, probs[0].ws);
 }
 
 __global__ void level_scores_kernel(LevelPtrs B, int stored, uint64_t *__restrict__ out)
@@ -976,7 +976,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
                                    tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr);
-            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
+            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
             if (!stored)
                 hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
             hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);

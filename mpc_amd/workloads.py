@@ -222,6 +222,18 @@ def config1_problem(depth=4, length_m=25.0, current=(0.0, 0.0)):
     return p, plan
 
 
+def semicircle_problem(length_s, current=(0.2, -0.1), weights=(1.0, 20.0, 5.0)):
+    """The reference's own end-to-end scenario (test/test_controller.cpp:449-467): LRL semicircle, rho 8 m, 2.5 m/s, plan
+    starting at t = 4, truncated to length_s seconds (the plan's length sets the search depth, controller.cpp:59-61);
+    start (0, 0) heading north at 2.5 m/s; reference-native 1-s levels.  -> (problem, depth)"""
+    w = DubinsWrapper((0.0, 0.0, math.pi / 2), (0.0, math.pi, 0.0), 8.0, LRL, 2.5, 4.0)
+    w.end_time = 4.0 + length_s
+    plan = DubinsPlan([w])
+    depth = plan.max_iterations(4.0)
+    return B.make_problem((0.0, 0.0, 0.0, 2.5), plan.checkpoints(4.0, depth), B.substep_schedule(1.0),
+                          last=(0.0, 0.0), current=current, weights=weights), depth
+
+
 def fleet_problems(n_problems, depth=20, base_seed=SEED, with_plans=False):
     """Config 5: independent vessels; per problem a random Dubins word, start perturbation and current.
     with_plans: also return the DubinsPlan objects (every plan starts at T0)."""

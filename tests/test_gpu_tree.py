@@ -361,7 +361,8 @@ def _leaf_controls(p, depth):
 @pytest.mark.parametrize("which", ["semicircle", "straight", "straight_with_current", "speed_only", "random"])
 def test_libm_tie_flag_is_the_two_ulp_test_on_the_strict_scores(solver, which):
     """mpc_tree_level.libm_tie / mpc_result.libm_tie (mpc_hip.h): set exactly when a level's strict runner-up lies within
-    MPC_TIE_ULPS = 2 ulps of its winner.  The expectation comes from the device's own strict scores of EVERY leaf: the
+    MPC_TIE_REL = 1e-12 of its winner, relative to max(score, 1 % of the weights' sum).  The expectation comes from the
+    device's own strict scores of EVERY leaf: the
     tree's leaves, enumerated on the host in DFS order, evaluated as an explicit candidate set in MPC_PREC_F64."""
     import torch
     depth = 3
@@ -398,10 +399,10 @@ def test_libm_tie_flag_is_the_two_ulp_test_on_the_strict_scores(solver, which):
         res = solver.eval_candidates(q, torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous(),
                                      torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous(), n, M.PREC_F64,
                                      M.SELECT_LAST_STEP, last, None)
-        bits = np.sort(last.cpu().numpy().view(np.int64))
-        assert bits[0] == int(np.float64(sl[l].best_score).view(np.int64)) and res.best_ordinal == sl[l].best_leaf
-        want = int(bits[1] - bits[0] <= 2)
-        assert sl[l].libm_tie == want and fl[l].libm_tie == want, (which, l, int(bits[1] - bits[0]))
+        c = np.sort(last.cpu().numpy())
+        assert c[0] == sl[l].best_score and res.best_ordinal == sl[l].best_leaf
+        want = _tie_expected(p, c)
+        assert sl[l].libm_tie == want and fl[l].libm_tie == want, (which, l, float(c[1] - c[0]))
         assert res.libm_tie == want                                # the candidate-set path reports the same flag
         seen.append(want)
     assert strict.libm_tie == fast.libm_tie == seen[-1]
@@ -410,9 +411,16 @@ def test_libm_tie_flag_is_the_two_ulp_test_on_the_strict_scores(solver, which):
         assert any(seen)          # the positive case is really exercised (observed: [1, 0, 1])
 
 
+def _tie_expected(p, sorted_costs):
+    """mpc_tie_limit of mpc_internal.h in the same IEEE operations: runner-up <= m + max(m, 1 % of the weights' sum) * 1e-12"""
+    m = np.float64(sorted_costs[0])
+    floor = np.float64(0.01) * (np.float64(p.w_distance) + np.float64(p.w_heading) + np.float64(p.w_speed))
+    return int(sorted_costs[1] <= m + (m if m > floor else floor) * np.float64(1.0e-12))
+
+
 def test_libm_tie_of_a_candidate_set_with_a_duplicated_winner(solver):
     """a candidate set in which the winner occurs twice: libm_tie in both precisions (equal scores: 0 ulps apart), the
-    lower ordinal wins; without the duplicate the flag follows the two-ulp test on the strict costs"""
+    lower ordinal wins; without the duplicate the flag follows the MPC_TIE_REL test on the strict costs"""
     import torch
     p = W.config2_problem(depth=8)
     n = 5000
@@ -421,8 +429,7 @@ def test_libm_tie_of_a_candidate_set_with_a_duplicated_winner(solver):
     d_t = torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous()
     last = torch.empty(n, dtype=torch.float64, device="cuda")
     base = solver.eval_candidates(p, d_r, d_t, n, M.PREC_F64, M.SELECT_LAST_STEP, last, None)
-    bits = np.sort(last.cpu().numpy().view(np.int64))
-    assert base.libm_tie == int(bits[1] - bits[0] <= 2)
+    assert base.libm_tie == _tie_expected(p, np.sort(last.cpu().numpy()))
     assert solver.eval_candidates(p, d_r, d_t, n, M.PREC_FAST).libm_tie == base.libm_tie
     w = int(base.best_ordinal)
     for other in (w + 1 if w + 1 < n else w - 1, (w + 2500) % n):          # in the winner's own workgroup, and in another

@@ -18,6 +18,28 @@ from helpers import oracle_args, rel_err, traj_array
 import oracle as O
 
 
+def draw(rng, max_depth=4):
+    """the next random problem of the stream -> (problem, depth, weights)"""
+    depth = int(rng.randint(2, max_depth + 1))
+    speed = float(rng.uniform(0.5, 2.75))
+    words = [(int(rng.randint(0, 4)), (float(rng.uniform(0.1, 1.5)), float(rng.uniform(0.5, 4.0)), float(rng.uniform(0.1, 1.5)))),
+             (W.LSL, (0.0, 40.0, 0.0))]
+    plan = W.chain(words, float(rng.uniform(6.0, 20.0)), speed, (float(rng.uniform(-100, 100)), float(rng.uniform(-100, 100)),
+                                                                  float(rng.uniform(0, 2 * math.pi))), W.T0)
+    cps = [plan.sample(W.T0 + (i + 1) * 1.0) for i in range(depth)]
+    x, y, heading, _ = plan.sample(W.T0)
+    start = (x + float(rng.uniform(-3, 3)), y + float(rng.uniform(-3, 3)), (heading + float(rng.uniform(-0.6, 0.6))) % (2 * math.pi),
+             float(rng.choice([0.0, rng.uniform(0.0, 2.75), rng.uniform(2.75, 3.5)])))
+    w = rng.uniform(0.0, 30.0, size=3) * (rng.uniform(size=3) > 0.15)
+    if not w.any():
+        w[0] = 1.0
+    p = M.make_problem(start, cps, M.substep_schedule(1.0), last=(float(rng.randint(-16, 17)) * 0.0625, float(rng.randint(0, 9)) * 0.125),
+                       current=(float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.8, 0.8))), weights=tuple(float(v) for v in w))
+    p.rudder_granularity = float(rng.choice([0.0625, 0.125, 0.25, 0.03125]))
+    p.throttle_granularity = float(rng.choice([0.125, 0.25, 0.0625]))
+    return p, depth, w
+
+
 def run(n_problems=200, seed=7, solver=None, verbose=True, max_depth=4):
     """-> dict(problems, bad = [disagreements that do NOT carry libm_tie], libm_ties = [flagged leaf disagreements], worst)"""
     rng = np.random.RandomState(seed)
@@ -25,23 +47,7 @@ def run(n_problems=200, seed=7, solver=None, verbose=True, max_depth=4):
     bad, flagged, worst = [], [], 0.0
     t0 = time.time()
     for k in range(n_problems):
-        depth = int(rng.randint(2, max_depth + 1))
-        speed = float(rng.uniform(0.5, 2.75))
-        words = [(int(rng.randint(0, 4)), (float(rng.uniform(0.1, 1.5)), float(rng.uniform(0.5, 4.0)), float(rng.uniform(0.1, 1.5)))),
-                 (W.LSL, (0.0, 40.0, 0.0))]
-        plan = W.chain(words, float(rng.uniform(6.0, 20.0)), speed, (float(rng.uniform(-100, 100)), float(rng.uniform(-100, 100)),
-                                                                      float(rng.uniform(0, 2 * math.pi))), W.T0)
-        cps = [plan.sample(W.T0 + (i + 1) * 1.0) for i in range(depth)]
-        x, y, heading, _ = plan.sample(W.T0)
-        start = (x + float(rng.uniform(-3, 3)), y + float(rng.uniform(-3, 3)), (heading + float(rng.uniform(-0.6, 0.6))) % (2 * math.pi),
-                 float(rng.choice([0.0, rng.uniform(0.0, 2.75), rng.uniform(2.75, 3.5)])))
-        w = rng.uniform(0.0, 30.0, size=3) * (rng.uniform(size=3) > 0.15)
-        if not w.any():
-            w[0] = 1.0
-        p = M.make_problem(start, cps, M.substep_schedule(1.0), last=(float(rng.randint(-16, 17)) * 0.0625, float(rng.randint(0, 9)) * 0.125),
-                           current=(float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.8, 0.8))), weights=tuple(float(v) for v in w))
-        p.rudder_granularity = float(rng.choice([0.0625, 0.125, 0.25, 0.03125]))
-        p.throttle_granularity = float(rng.choice([0.125, 0.25, 0.0625]))
+        p, depth, w = draw(rng, max_depth)
         cfg, veh, ocps, sub = oracle_args(p)
         it, traj, olev, nodes = O.mpc_tree(cfg, O.State(p.start_x, p.start_y, p.start_heading, p.start_speed, 0.0), ocps, depth, -1)
         results = []
