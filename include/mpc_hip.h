@@ -209,8 +209,10 @@ int         mpc_hip_run_candidates(mpc_hip_handle *h, const float *d_rudders, co
                                    uint64_t n, int precision, int selection,
                                    double *d_cost_last, double *d_cost_cum);
 /* mpc_hip_run_seeded for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (it has no device): this entry
- * point exists for callers that must not reach hipMalloc / hipFree -- code under HIP graph capture, tight serving
- * loops, harnesses that forbid allocation.  Same arguments, same kernels, same results in the same places
+ * point exists for callers that must not reach hipMalloc / hipFree -- tight serving loops, harnesses that forbid
+ * allocation, code that wants its device footprint fixed before it starts capturing HIP graphs (what the call guarantees
+ * is the absence of allocation, asserted by tests/test_zz_no_alloc.py through hipMemGetInfo; launching it INSIDE an active
+ * stream capture has not been exercised: it sets the device and attaches events to its dispatches when timing is on).  Same arguments, same kernels, same results in the same places
  * (mpc_hip_fetch_results, device winners, winner sink, d_cost_*) as mpc_hip_run_seeded, bit for bit; what differs is
  * where the working memory lives: the candidates' keys and the rollout workgroups' (key, ordinal, near-tie count)
  * triples are kept in a fixed device array inside the library (8.6 MB, held by every GPU the library has created a
@@ -333,6 +335,11 @@ int         mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_ga
  * mpc_hip_timing, mpc_hip_synchronize, mpc_hip_upload_problems*, mpc_hip_set_model, mpc_hip_estimate_currents,
  * mpc_hip_set_pipeline(h, 0), and mpc_hip_flush, for callers that consume the winner sink on the stream (flush before
  * the collective that reads it).  The winner sink in force when a run was ENQUEUED is the one its finish writes.
+ * What a DEFERRED finish still reads of the caller's memory: the explicit control arrays of its run (d_rudders /
+ * d_throttles: the strict decision among near-tied candidates and the winner's trajectory and record take the controls
+ * from there) and the winner sink.  They must therefore stay UNCHANGED until the next run has been enqueued or
+ * mpc_hip_flush has been called -- at level 1 already, not only at level 2: a sampling loop that rewrites its control
+ * buffer in place between runs calls mpc_hip_flush first (with the pipeline off nothing is deferred and nothing is kept).
  * Results are bit for bit those of the two-kernel form.  The one-call forms (mpc_hip_eval_*) fetch and therefore
  * never defer; runs that have no fused variant (strict precision, non-uniform schedules, >= 2^20 candidates) finish
  * the pending solve with a launch of its own first.  Off by default.  No counterpart in the reference.

@@ -47,17 +47,34 @@ def test_default_line_has_the_contract_keys():
     assert r["algorithmic_flop_per_launch"] == 2 * 65536 * 20 * (54 * 20 + 21)
     # the kernel's time (HIP events on the dispatches) accounts for the region: 20 launches of two solves
     assert 0.85 * d["ms_per_step"] <= d["rollout_kernel_ms"] / 2 <= 1.05 * d["ms_per_step"]
+    # a stream of DISTINCT solves: four candidate sets in turn, the CPU baseline checks the GPU's choice for every one
+    assert d["config"]["distinct_candidate_sets"] == 4 and len(d["chosen"]["per_set"]) == 4
+    assert len({c["ordinal"] for c in d["chosen"]["per_set"]}) == 4
+    assert c["same_choice_per_set"] == [True] * 4
+    assert d["chosen"]["ordinal"] == d["chosen"]["per_set"][(40 - 1) % 4]["ordinal"]
+    # the production path (the reference-native tree search through the C-ABI) is in the line
+    t = d["tree"]
+    for name in ("lrl_semicircle", "config1_straight_line"):
+        sc = t["scenarios"][name]
+        for depth in ("3", "4", "5", "7"):
+            row = sc["depth"][depth]
+            assert row["strict_and_fast_agree"] is True and 0 < row["strict_p50_ms"] < 100 and 0 < row["fast_p50_ms"] < 100
+            if depth != "7":
+                assert row["same_first_control"] is True and row["cpu_ms"] > row["strict_p50_ms"]
+        assert sc["deepest_level_inside_budget"]["fast"]["levels"] >= 6 and sc["deepest_level_inside_budget"]["strict"]["levels"] >= 6
+        assert sc["cpu_deepest_level_inside_budget"] <= 5
+    assert t["scenarios"]["lrl_semicircle"]["depth"]["4"]["first_control"] == [-0.0625, 1.0]     # SURVEY.md 8c's probe of the reference
 
 
 def test_an_odd_region_runs_one_solve_per_launch():
-    d = _bench("--steps", "41", "--warmup", "5", "--no-cpu-baseline")
+    d = _bench("--steps", "41", "--warmup", "5", "--no-cpu-baseline", "--no-tree")
     assert d["config"]["pipeline_level"] == 1 and d["config"]["solves_per_launch"] == 1
     assert d["roofline"]["kernel"] == "rollout_kernel" and d["roofline"]["algorithmic_flop_per_launch"] == 65536 * 20 * (54 * 20 + 21)
 
 
 def test_two_kernel_form_and_rccl_rehearsal_choose_the_same_control():
-    a = _bench("--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-pipeline")
-    b = _bench("--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--force-collective", "--combine-batch", "16")
+    a = _bench("--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-tree", "--no-pipeline")
+    b = _bench("--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-tree", "--force-collective", "--combine-batch", "16")
     assert a["chosen"]["ordinal"] == b["chosen"]["ordinal"] == b["chosen"]["global_ordinal_after_combine"]
     assert (a["chosen"]["rudder"], a["chosen"]["throttle"]) == (b["chosen"]["rudder"], b["chosen"]["throttle"])
     assert b["rccl_ranks"] == 1 and a["rccl_ranks"] is None and b["chosen"]["cross_shard_near_tie_rows"] == 0
@@ -74,7 +91,7 @@ def test_two_ranks_on_one_gpu_over_gloo_rehearsal():
     """`bench.py --gpus 2 --backend gloo --same-device`: the N-rank bench path (self-launch, barriers, max over ranks,
     ShardCombiner's batched exchange and exact combine) end to end on a 1-GPU box.  The ranks time-share cuda:0, so the
     line is a rehearsal, and says so; what is asserted is the plumbing and the choice."""
-    a = _bench("--steps", "20", "--warmup", "4", "--no-cpu-baseline", "--repeats", "5")
+    a = _bench("--steps", "20", "--warmup", "4", "--no-cpu-baseline", "--no-tree", "--repeats", "5")
     d = _bench("--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "20", "--warmup", "4", "--repeats", "5",
                "--combine-batch", "8")
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["rccl_ranks"] is None

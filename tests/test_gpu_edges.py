@@ -217,6 +217,10 @@ def test_misuse_of_the_stream_and_multi_gpu_entry_points_is_refused():
             s.combine_shards_exact(buf, 2, 3, 6, 0, out)      # rows must be solves x problems
         with pytest.raises(M.MpcError):
             s.combine_shards_exact(buf, 2, 2, 5, 0, out)      # records shallower than the problems
+        with pytest.raises(M.MpcError):
+            s.combine_shards_exact(buf, 2, 2, 6, 0, out, precision=7)        # the records' precision / selection are arguments
+        with pytest.raises(M.MpcError):
+            s.combine_shards_exact(buf, 2, 2, 6, 0, out, selection=-1)
         # and the well-formed call right after still works: two shards holding the same records -> the lower shard wins ties
         s.copy_winner_records(buf[:2 * M.winner_record_words(6)], 6)
         W6 = M.winner_record_words(6)

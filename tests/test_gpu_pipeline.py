@@ -178,3 +178,48 @@ def test_winner_record_sink_carries_the_winners_controls(pipeline):
         solver.set_pipeline(False)
     finally:
         solver.close()
+
+
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_a_control_buffer_rewritten_between_runs_needs_a_flush_first(pipeline):
+    """include/mpc_hip.h, the deferred finish: a run's explicit control arrays are still read by its PENDING finish (the
+    strict decision among near-ties, the winner's trajectory and record), so a sampling loop that rewrites ONE control
+    buffer in place calls mpc_hip_flush before each rewrite.  Done that way, every run's record and result are what the
+    same set gives when solved alone -- at every pipeline level."""
+    torch = _torch()
+    p = W.config2_problem(depth=8)
+    n, rounds = 4096, 5
+    host = [W.seeded_controls(W.SEED + 40 + k, 0, n, 8, p.last_rudder, p.last_throttle) for k in range(rounds)]
+    alone = M.Solver(0)
+    want = []
+    for rud, thr in host:
+        r = alone.eval_candidates(p, torch.tensor(rud, dtype=torch.float32, device="cuda").contiguous(),
+                                  torch.tensor(thr, dtype=torch.float32, device="cuda").contiguous(), n, M.PREC_FAST)
+        want.append((int(r.best_ordinal), r.best_last, [r.trajectory[l + 1].rudder for l in range(8)], traj_array(r).tobytes()))
+    alone.close()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):                               # the rewrites (torch copies) run on the solver's stream
+        solver = M.Solver(0, stream=stream.cuda_stream)
+        solver.upload([p], [W.SEED])
+        solver.set_pipeline(pipeline)
+        d_r = torch.empty((8, n), dtype=torch.float32, device="cuda")
+        d_t = torch.empty((8, n), dtype=torch.float32, device="cuda")
+        W8 = M.winner_record_words(8)
+        recs = torch.zeros((rounds, W8), dtype=torch.int64, device="cuda")
+        last = None
+        for k, (rud, thr) in enumerate(host):
+            solver.flush()                                        # BEFORE the buffer changes: the pending finish reads it
+            d_r.copy_(torch.tensor(rud, dtype=torch.float32), non_blocking=False)
+            d_t.copy_(torch.tensor(thr, dtype=torch.float32), non_blocking=False)
+            solver.set_winner_record_sink(recs[k], 8)
+            solver.run_candidates(d_r, d_t, n, M.PREC_FAST)
+        last = solver.fetch()[0]
+        solver.set_winner_record_sink(None, 8)
+        torch.cuda.synchronize()
+        got = recs.cpu().numpy()
+        for k in range(rounds):
+            assert int(got[k, 1]) == want[k][0], (pipeline, k)
+            assert got[k, 0] == np.float64(want[k][1]).view(np.int64)
+            assert [float(v) for v in got[k, 2::2].view(np.float64)] == want[k][2]
+        assert traj_array(last).tobytes() == want[-1][3]
+        solver.close()

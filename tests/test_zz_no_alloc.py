@@ -104,3 +104,37 @@ def test_static_entry_point_rejects_what_does_not_fit():
         assert a == [(r.best_ordinal, r.best_last) for r in solver.fetch()] and len(set(a)) == 1
     finally:
         solver.close()
+
+
+def test_static_entry_point_allocates_nothing():
+    """The property the entry point is named for: device memory in use (hipMemGetInfo, through torch.cuda.mem_get_info)
+    does not move across the FIRST static call of a fresh handle -- a call larger than anything that handle has run,
+    which would make mpc_hip_run_seeded grow its keys / triples / snapshot buffers -- nor across a second, different one.
+    (The kernels' code objects are loaded beforehand by another handle: loading code is not what is being measured.)"""
+    torch = _torch()
+    p = W.config2_problem(depth=12)
+    warm = M.Solver(0)
+    warm.upload([p], [W.SEED])
+    warm.run_seeded_static(0, 70000, M.PREC_FAST)
+    warm.run_seeded_static(0, 70000, M.PREC_F64)
+    warm.fetch()
+    solver = M.Solver(0)
+    try:
+        solver.upload([p], [W.SEED])                             # allocates (documented): the problems must be resident
+        solver.synchronize()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        solver.run_seeded_static(0, 1 << 20, M.PREC_FAST)        # 2^20 candidates: 8 MB of keys if it were to allocate them
+        solver.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        solver.run_seeded_static(5, 300000, M.PREC_F64)
+        solver.synchronize()
+        free2 = torch.cuda.mem_get_info()[0]
+        assert free1 == free0 and free2 == free0, (free0, free1, free2)
+        # the allocating entry point, for contrast, does grow its buffers on such a call (the check can see an allocation)
+        solver.run_seeded(0, 1 << 20, M.PREC_FAST)
+        solver.synchronize()
+        assert torch.cuda.mem_get_info()[0] < free0
+    finally:
+        solver.close()
+        warm.close()
