@@ -209,9 +209,10 @@ def main():
                          "covered, at most 2000 regions")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="two kernels per solve (rollouts, finish) instead of the deferred finish (mpc_hip_set_pipeline)")
-    ap.add_argument("--pipeline-level", type=int, choices=[0, 1, 2], default=2,
-                    help="mpc_hip_set_pipeline: 1 = every solve's finish rides in the next solve's rollout launch; 2 = also two "
-                         "solves per launch (a 65,536-candidate set is one wave per SIMD: the second wave comes from the next solve)")
+    ap.add_argument("--pipeline-level", type=int, choices=[0, 1, 2, 3, 4], default=4,
+                    help="mpc_hip_set_pipeline: 1 = every solve's finish rides in the next solve's rollout launch; K >= 2 = also K "
+                         "solves per launch (a 65,536-candidate set is one wave per SIMD: the second wave comes from the next solve, "
+                         "and a launch's fixed ~10 us are paid once per K solves)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL combine step even with one rank (rehearsal of the N > 1 path on a 1-GPU box)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -345,11 +346,11 @@ def main():
         # a stream of solves: each run's finish rides in the next run's rollout launch (one dispatch per solve); the
         # results are bit for bit those of the two-kernel form (tests/test_gpu_pipeline.py)
         level = 0 if args.no_pipeline else args.pipeline_level
-        if level == 2 and args.steps % 2:
-            level = 1          # an odd region would end in a one-solve launch and blur the per-launch kernel time: one solve per launch then
+        while level >= 2 and args.steps % level:
+            level -= 1         # a region that is not a whole number of launches would end in a smaller launch and blur the per-launch kernel time
         solver.set_pipeline(level)
-        # solves per rollout launch: level 2 pairs the one-wave-per-SIMD solves of config 2 (fast precision) and nothing else
-        spl = 2 if (level == 2 and args.workload == "config2" and prec == M.PREC_FAST) else 1
+        # solves per rollout launch: levels >= 2 group the one-wave-per-SIMD solves of config 2 (fast precision) and nothing else
+        spl = level if (level >= 2 and args.workload == "config2" and prec == M.PREC_FAST) else 1
         solver.set_timing(0)
         t_ramp = time.perf_counter()
         while time.perf_counter() - t_ramp < args.ramp_seconds and args.workload == "config2":
@@ -400,7 +401,7 @@ def main():
         runs, k1_ms_sum, total_ms_sum = solver.timing(reset=True)
         # for the record: the same regions with ONE solve per launch (pipeline level 1), not part of `value`
         one_per_launch = None
-        if spl == 2:
+        if spl >= 2:
             solver.set_pipeline(1)
             solver.set_timing(0)
             for _ in range(4):
@@ -472,9 +473,10 @@ def main():
                        "precision": args.precision + (" (FP64 state, streamlined model, FP32 atan2 in the cost)" if prec == M.PREC_FAST else " (reference statement order)"),
                        "selection": "last_step", "deferred_finish": level >= 1, "pipeline_level": level, "solves_per_launch": spl,
                        "distinct_candidate_sets": (n_sets if args.workload == "config2" else None),
-                       "stream": (("%d independent solves share each rollout launch (mpc_hip_set_pipeline level 2): a 65,536-candidate set is one "
-                                   "wave per SIMD, the second wave comes from the NEXT solve of the stream -- a different candidate set with its own "
-                                   "control arrays and outputs; `one_solve_per_launch` gives the rate without it" % spl) if spl > 1 else
+                       "stream": (("%d independent solves share each rollout launch (mpc_hip_set_pipeline level %d): a 65,536-candidate set is one "
+                                   "wave per SIMD, the second wave comes from the NEXT solves of the stream -- different candidate sets with their own "
+                                   "control arrays and outputs -- and a launch's fixed cost is paid once; `one_solve_per_launch` gives the rate "
+                                   "without it" % (spl, spl)) if spl > 1 else
                                   "one solve per rollout launch"),
                        "parallelism": ("candidate shards; per %d solves ONE async RCCL all-gather of the winner records (score, ordinal, controls), then "
                                        "mpc_hip_combine_shards_exact: strict re-score of cross-shard near-ties from the gathered controls, "
@@ -497,7 +499,7 @@ def main():
                 "bound": "valu",
                 "bound_note": "FP64 vector ALU (SURVEY.md 8d): neither mfma nor hbm -- sequential per-candidate ODE "
                               "integration, no dense contraction; HBM figures under 'hbm'",
-                "kernel": "rollout_pair_kernel" if spl == 2 else "rollout_kernel", "solves_per_launch": spl, "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "kernel": "rollout_group_kernel" if spl >= 2 else "rollout_kernel", "solves_per_launch": spl, "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flop / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": measured_traffic(spl) if args.workload == "config2" and prec == M.PREC_FAST else None,
                 "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",

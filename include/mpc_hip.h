@@ -343,14 +343,16 @@ int         mpc_hip_combine_shards_exact(mpc_hip_handle *h, const uint64_t *d_ga
  * Results are bit for bit those of the two-kernel form.  The one-call forms (mpc_hip_eval_*) fetch and therefore
  * never defer; runs that have no fused variant (strict precision, non-uniform schedules, >= 2^20 candidates) finish
  * the pending solve with a launch of its own first.  Off by default.  No counterpart in the reference.
- * Level 2 (on == 2) adds TWO RUNS PER LAUNCH: a 65,536-candidate set is one wave per SIMD, and a lone wave issues an
- * instruction every ~6.2 cycles where the SIMD could take one every 4 -- the second wave can only come from another
- * solve.  A run that can pair up (MPC_PREC_FAST, uniform substeps, fewer than 2^20 candidates) is only PREPARED by its
- * call and goes to the GPU together with the next such run, in one dispatch that also carries the finish workgroups of
- * the two runs before (+10-15 % on a stream of 65,536-candidate solves).  What changes for the caller: the device arrays
- * a run reads and writes (controls, cost outputs, winner sink) are used from the stream position of the NEXT run -- or
- * of the call that asks for results, which sends a run without a partner alone -- so they must stay as they are
- * until then; everything else is as at level 1, results bit for bit. */
+ * Levels 2, 3, 4 (on == K) add K RUNS PER LAUNCH: a 65,536-candidate set is one wave per SIMD, and a lone wave issues
+ * an instruction every ~6.2 cycles where the SIMD could take one every 4 -- the second wave can only come from another
+ * solve -- and every launch of a stream costs ~10 us whatever it holds (the boundary between dependent dispatches, the
+ * workgroups' prologue, the tail), which a launch of four solves pays once.  A run that can share a launch (MPC_PREC_FAST,
+ * uniform substeps, fewer than 2^20 candidates) is only PREPARED by its call; the K-th such run sends the whole group to
+ * the GPU in one dispatch that also carries the finish workgroups of the group before (level 2: +10-15 % on a stream of
+ * 65,536-candidate solves, level 4: a further +6 %).  What changes for the caller: the device arrays a run reads and
+ * writes (controls, cost outputs, winner sink) are used from the stream position of the run that COMPLETES its group -- or
+ * of the call that asks for results, which sends an incomplete group as it is -- so they must stay as they are until
+ * then; everything else is as at level 1, results bit for bit. */
 int         mpc_hip_set_pipeline(mpc_hip_handle *h, int on);
 int         mpc_hip_flush(mpc_hip_handle *h);
 /* Which runs carry HIP events: every `period`-th run of the handle (1 = all, the default; 0 = none).  The events

@@ -410,7 +410,7 @@ class Solver:
 
     def set_pipeline(self, on):
         """deferred finish for streams of solves (mpc_hip.h): run n's results appear with run n+1 or on demand"""
-        _check(self._L.mpc_hip_set_pipeline(self._h, int(on)))      # False/0 off, True/1 deferred finish, 2 two runs per launch
+        _check(self._L.mpc_hip_set_pipeline(self._h, int(on)))      # False/0 off, True/1 deferred finish, K = 2..4: K runs per launch
 
     def flush(self):
         """launch a pending finish now (before a collective that reads the winner sink on the stream)"""

@@ -357,7 +357,7 @@ extern "C" int mpc_hip_upload_problems(mpc_hip_handle *h, const mpc_problem *h_p
  * needs the results (fetch, winners, upload, synchronize, ...) launches it on its own first.  Working memory that K1
  * writes and K2 reads is double-buffered (h->wm[0..1]; level 2 rotates over all four sets) so that K1 of solve n+1 never
  * overwrites what K2 of solve n reads. */
-static int launch_pair(mpc_hip_handle *h, const StashedRun *second);
+static int launch_group(mpc_hip_handle *h);
 
 /* K2's workgroup: 256 lanes reduce up to 1024 workgroup triples per trip; a problem with few of them (a fleet: 32 per
  * vessel) gets ONE wave -- its finish is one lane rolling the winner out again, and 4096 such workgroups of four waves
@@ -373,19 +373,22 @@ static int finish_standalone(mpc_hip_handle *h, const StashedRun &r)
     return MPC_OK;
 }
 
-/* level 2's part: the run waiting for a partner and the finishes of the last launch's runs */
+/* level >= 2's part: the runs waiting for their group to fill and the finishes of the last launch's runs */
 static int flush_pairs(mpc_hip_handle *h)
 {
-    if (h->stashed) { if (int s = launch_pair(h, nullptr)) return s; }      /* a run without a partner goes alone */
-    if (h->n_pend2 == 2) {                                                  /* the two runs of one launch: one launch for both */
-        const dim3 grid(h->pend2[0].n_probs, 2), blk(finish_block(std::max(h->pend2[0].fin.nblk, h->pend2[1].fin.nblk)));   /* (they write different result buffers) */
-        if (h->pend2[0].seeded) hipLaunchKernelGGL((finish2_kernel<true>), grid, blk, 0, h->stream, h->pend2[0].fin, h->pend2[1].fin);
-        else hipLaunchKernelGGL((finish2_kernel<false>), grid, blk, 0, h->stream, h->pend2[0].fin, h->pend2[1].fin);
+    if (h->n_stash) { if (int s = launch_group(h)) return s; }              /* an incomplete group goes as it is */
+    if (h->n_pendg > 1) {                                                   /* the runs of one launch: one launch for all their finishes */
+        FinishGroup G{};
+        uint32_t nblk = 0;
+        for (int i = 0; i < h->n_pendg; i++) { G.f[i] = h->pendg[i].fin; nblk = std::max(nblk, h->pendg[i].fin.nblk); }
+        const dim3 grid(h->pendg[0].n_probs, (uint32_t)h->n_pendg), blk(finish_block(nblk));   /* (only the newest writes the handle's result buffers) */
+        if (h->pendg[0].seeded) hipLaunchKernelGGL((finish_group_kernel<true>), grid, blk, 0, h->stream, G);
+        else hipLaunchKernelGGL((finish_group_kernel<false>), grid, blk, 0, h->stream, G);
         HIP_TRY(hipGetLastError());
-    } else if (h->n_pend2 == 1) {
-        if (int s = finish_standalone(h, h->pend2[0])) return s;
+    } else if (h->n_pendg == 1) {
+        if (int s = finish_standalone(h, h->pendg[0])) return s;
     }
-    h->n_pend2 = 0;
+    h->n_pendg = 0;
     return MPC_OK;
 }
 
@@ -415,45 +418,54 @@ static int ensure_buffer(mpc_hip_handle *h, void **buf, size_t *cap, size_t need
     return MPC_OK;
 }
 
-/* ---- two runs per launch (mpc_hip_set_pipeline level 2) ---------------------------------------------------------
+/* ---- several runs per launch (mpc_hip_set_pipeline level K = 2 .. MPC_GROUP_MAX) ----------------------------------
  * A 65,536-candidate set is one wave per SIMD; the second wave a SIMD needs to issue a VALU instruction every 4 cycles
- * instead of every ~6.2 can only come from another solve.  At level 2 a run that can pair up (fast, uniform substeps,
- * one-wave workgroups) is only PREPARED by its call and launched together with the next such run, in one dispatch that
- * also carries the finish workgroups of the launch before (rollout_pair_kernel); a run without a partner goes alone
- * when anything asks for results (flush_pending).  Working memory rotates over four sets: the two runs being launched
- * and the two whose finishes ride along. */
-static int launch_pair(mpc_hip_handle *h, const StashedRun *second)
+ * instead of every ~6.2 can only come from another solve, and the ~10 us a launch costs whatever it holds (dispatch
+ * boundary, prologue, tail) are paid once per launch.  At level K a run that can share a launch (fast, uniform substeps,
+ * one-wave workgroups) is only PREPARED by its call; the K-th such run launches the whole group in one dispatch that also
+ * carries the finish workgroups of the launch before (rollout_group_kernel); an incomplete group goes as it is when
+ * anything asks for results (flush_pending).  Working memory rotates over 2 K sets: the runs being launched and the
+ * runs whose finishes ride along. */
+static int launch_group(mpc_hip_handle *h)
 {
-    const StashedRun first = h->stash;
-    h->stashed = false;
+    const int n = h->n_stash;
+    StashedRun run[MPC_GROUP_MAX];
+    for (int i = 0; i < n; i++) run[i] = h->stash[i];
+    h->n_stash = 0;
     /* finishes that cannot ride along (another candidate source or batch size) go first, on their own */
-    if (h->n_pend2 && (h->pend2[0].seeded != first.seeded || h->pend2[0].n_probs != first.n_probs)) {
-        for (int i = 0; i < h->n_pend2; i++)
-            if (int s = finish_standalone(h, h->pend2[i])) return s;
-        h->n_pend2 = 0;
+    if (h->n_pendg && (h->pendg[0].seeded != run[0].seeded || h->pendg[0].n_probs != run[0].n_probs)) {
+        for (int i = 0; i < h->n_pendg; i++)
+            if (int s = finish_standalone(h, h->pendg[i])) return s;
+        h->n_pendg = 0;
     }
-    PairArgs A{};
-    A.run[0] = first.run;
-    if (second) A.run[1] = second->run;                  /* else nblk == 0: no workgroups */
-    for (int i = 0; i < h->n_pend2; i++) A.prev[i] = h->pend2[i].fin;
-    const uint32_t n_prev = (uint32_t)h->n_pend2;
-    const dim3 grid(A.run[0].nblk + A.run[1].nblk + n_prev, first.n_probs), blk(64);
-    const size_t lds = second ? std::max(first.lds, second->lds) : first.lds;
-    const StashedRun *t = first.timed ? &first : (second && second->timed ? second : nullptr);   /* one pair of events per dispatch */
+    GroupArgs A{};
+    uint32_t end = 0;
+    size_t lds = 0;
+    const StashedRun *t = nullptr;                       /* one pair of events per dispatch: the first timed run's */
+    for (int i = 0; i < MPC_GROUP_MAX; i++) {
+        if (i < n) {
+            A.run[i] = run[i].run;
+            end += run[i].run.nblk;
+            lds = std::max(lds, run[i].lds);
+            if (!t && run[i].timed) t = &run[i];
+        }
+        A.end[i] = end;                                  /* unused runs: no workgroups */
+    }
+    for (int i = 0; i < h->n_pendg; i++) A.prev[i] = h->pendg[i].fin;
+    const uint32_t n_prev = (uint32_t)h->n_pendg;
+    const dim3 grid(end + n_prev, run[0].n_probs), blk(64);
     hipEvent_t k1a = t ? h->ev[4 * t->slot] : nullptr, k1b = t ? h->ev[4 * t->slot + 1] : nullptr;
-    h->timed[first.slot] = t == &first;
-    if (second) h->timed[second->slot] = t == second;
+    for (int i = 0; i < n; i++) h->timed[run[i].slot] = t == &run[i];
     if (t) h->total_from_k1[t->slot] = 1;                /* the finishes have no dispatch of their own */
-    if (first.seeded) hipExtLaunchKernelGGL((rollout_pair_kernel<true>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A);
-    else hipExtLaunchKernelGGL((rollout_pair_kernel<false>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A);
+    if (run[0].seeded) hipExtLaunchKernelGGL((rollout_group_kernel<true>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A);
+    else hipExtLaunchKernelGGL((rollout_group_kernel<false>), grid, blk, lds, h->stream, k1a, k1b, 0, h->d_probs, A);
     HIP_TRY(hipGetLastError());
-    h->n_pend2 = 0;
-    h->pend2[h->n_pend2] = first;
-    if (second) {                                        /* two finishes in one launch: only the newer writes the handle's results */
-        h->pend2[0].fin.results = h->d_results_alt; h->pend2[0].fin.winners = h->d_winners_alt;
-        h->pend2[1] = *second;
-        h->n_pend2 = 2;
-    } else h->n_pend2 = 1;
+    /* several finishes in one launch: only the newest run's writes the handle's results */
+    for (int i = 0; i < n; i++) {
+        h->pendg[i] = run[i];
+        if (i + 1 < n) { h->pendg[i].fin.results = h->d_results_alt; h->pendg[i].fin.winners = h->d_winners_alt; }
+    }
+    h->n_pendg = n;
     return MPC_OK;
 }
 
@@ -506,11 +518,11 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
             if (h->h_probs[p].sub[s * SUB_STRIDE] != h->h_probs[p].sub[0]) { uniform = false; break; }
     /* level 2 pairs up what the pair kernel has a variant for; any other run is treated as at level 1 */
     const bool pipelined = h->pipeline && !use_static;
-    const bool pairable = pipelined && h->pipeline == 2 && fast && uniform && block == 64;
+    const bool pairable = pipelined && h->pipeline >= 2 && fast && uniform && block == 64;
     if (!pipelined || (pairable && h->pending)) { if (int s = flush_pending(h)) return s; }
     else if (!pairable) { if (int s = flush_pairs(h)) return s; }
     /* which set of the working memory this run writes: the others may still be read by pending finishes */
-    const int half = pairable ? (int)(h->wm_rr++ & 3u) : pipelined ? (h->pending ? 1 - h->pend_half : 0) : 0;
+    const int half = pairable ? (int)(h->wm_rr++ % (2u * MPC_GROUP_MAX)) : pipelined ? (h->pending ? 1 - h->pend_half : 0) : 0;
     WorkMem &wm = h->wm[half];
     double *d_keys; uint64_t *d_pkey, *d_pord; uint32_t *d_pcnt;
     if (use_static) {
@@ -593,12 +605,11 @@ static int run_common(mpc_hip_handle *h, bool seeded, const float *d_rud, const 
                              fin, seeded, timed, lds, h->n_probs, slot};
         h->timed[slot] = false;                                         /* set by the launch that carries the events */
         int s = MPC_OK;
-        if (h->stashed && h->stash.seeded == seeded && h->stash.n_probs == h->n_probs)
-            s = launch_pair(h, &rec);
-        else {
-            if (h->stashed) s = launch_pair(h, nullptr);
-            h->stash = rec; h->stashed = true;
-        }
+        /* a run of another kind (candidate source, batch size) does not share a launch with the waiting ones */
+        if (h->n_stash && (h->stash[0].seeded != seeded || h->stash[0].n_probs != h->n_probs)) s = launch_group(h);
+        if (s) return s;
+        h->stash[h->n_stash++] = rec;
+        if (h->n_stash >= std::min(h->pipeline, MPC_GROUP_MAX)) s = launch_group(h);
         if (s) return s;
         h->runs++;
         h->last_count = count; h->last_first = first; h->last_precision = precision; h->last_selection = selection;
@@ -664,7 +675,7 @@ extern "C" int mpc_hip_set_pipeline(mpc_hip_handle *h, int on)
 {
     if (!h) { mpc_set_err("handle is NULL"); return MPC_ERR_INVALID; }
     if (int s = mpc_use_device(h)) return s;
-    if (on < 0 || on > 2) { mpc_set_err("set_pipeline: level out of range [0, 2]"); return MPC_ERR_INVALID; }
+    if (on < 0 || on > MPC_GROUP_MAX) { mpc_set_err("set_pipeline: level out of range [0, 4]"); return MPC_ERR_INVALID; }
     if (on != h->pipeline) { if (int s = flush_pending(h)) return s; }
     h->pipeline = on;
     return MPC_OK;

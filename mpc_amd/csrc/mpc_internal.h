@@ -99,7 +99,9 @@ struct FinishArgs {
     int snap_shift;                 /* snapshots hold every 2^shift-th level */
     DevResult *results;
 };
-/* what K1 needs of one run: rollout_pair_kernel (mpc_hip_set_pipeline level 2) takes two of these */
+/* how many runs one rollout launch can hold (mpc_hip_set_pipeline level = runs per launch, 2 .. MPC_GROUP_MAX) */
+#define MPC_GROUP_MAX 4
+/* what K1 needs of one run: rollout_group_kernel takes up to MPC_GROUP_MAX of these */
 struct RunArgs {
     const float *rud, *thr;
     uint64_t first, count;
@@ -152,15 +154,15 @@ struct mpc_hip_handle {
     uint64_t *d_pkey2 = nullptr;                                /* tree search: every expansion workgroup's runner-up key (libm_tie) */
     uint32_t *d_pcnt = nullptr;
     size_t cap_partials = 0;
-    WorkMem wm[4];                                              /* keys, snapshots (and the triples of all but wm[0]); level 1 uses two, level 2 four */
+    WorkMem wm[2 * MPC_GROUP_MAX];                              /* keys, snapshots (and the triples of all but wm[0]); level 1 uses two, level K >= 2 uses 2 K */
     /* deferred finish (mpc_hip.hip) */
-    int pipeline = 0;                                           /* 0 off, 1 deferred finish, 2 two runs per launch + deferred finish */
+    int pipeline = 0;                                           /* 0 off, 1 deferred finish, K >= 2: K runs per launch + deferred finish */
     bool pending = false, pend_seeded = false, pend_timed = false;
-    /* level 2: a run waiting for its partner, and the (<= 2) runs of the last launch whose finishes are pending */
-    bool stashed = false;
-    StashedRun stash;
-    int n_pend2 = 0;
-    StashedRun pend2[2];
+    /* level >= 2: the runs waiting for their group to fill, and the runs of the last launch whose finishes are pending */
+    int n_stash = 0;
+    StashedRun stash[MPC_GROUP_MAX];
+    int n_pendg = 0;
+    StashedRun pendg[MPC_GROUP_MAX];
     uint32_t wm_rr = 0;
     DevResult *d_results_alt = nullptr;                         /* where the OLDER of two finishes in one launch writes */
     uint64_t *d_winners_alt = nullptr;

@@ -102,7 +102,9 @@ __device__ inline double clampd(double v, double lo, double hi) { return v < lo 
  * a run whose result is wanted at once -- K2 then only reads (6 us instead of 12 on config 2), and nobody counts the 84
  * MB K1 writes in 39 us; every 4th (shift 2, 21 MB: the problem's own bytes are 12 MB) for a stream of solves, whose
  * finish rides under the next rollout launch where its extra 6 us cost nothing, and for sets too big for every level. */
+#ifndef SNAP_SHIFT_STREAM
 #define SNAP_SHIFT_STREAM 2
+#endif
 __host__ __device__ inline int snap_slots(int depth, int shift) { return depth >> shift; }
 /* K1's side.  The stores are buffer stores with the WRITE-THROUGH cache policy (sc0 sc1): 94 MB of snapshots per
  * config-2 solve otherwise sit dirty in the XCDs' L2s until the end-of-kernel write-back, which then delays the
@@ -515,14 +517,16 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs A)
     finish_body<SEEDED, 4>(A, blockIdx.x, lds, s_list, small);
 }
 
-/* the finishes of the two runs of one launch (mpc_hip_set_pipeline level 2), when nothing follows to carry them */
+/* the finishes of the (<= MPC_GROUP_MAX) runs of one launch (mpc_hip_set_pipeline level >= 2), when nothing follows to
+ * carry them: blockIdx.y picks the run */
+struct FinishGroup { FinishArgs f[MPC_GROUP_MAX]; };
 template <bool SEEDED>
-__global__ __launch_bounds__(256) void finish2_kernel(const FinishArgs a, const FinishArgs b)
+__global__ __launch_bounds__(256) void finish_group_kernel(const FinishGroup G)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t s_list[LIST_CAP];
     __shared__ uint64_t small[FINISH_LDS_WORDS];
-    finish_body<SEEDED, 4>(blockIdx.y ? b : a, blockIdx.x, lds, s_list, small);
+    finish_body<SEEDED, 4>(G.f[blockIdx.y], blockIdx.x, lds, s_list, small);
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -649,30 +653,37 @@ __global__ __launch_bounds__(256) void rollout_kernel(const DevProblem *__restri
                                                 snap_base, snap_depth, snap_shift, pkey, pord, pcnt, blockIdx.x, n_rollout_blocks, lds);
 }
 
-/* Two runs in ONE launch (mpc_hip_set_pipeline level 2).  A 65,536-candidate set is one wave per SIMD, and a lone wave
- * issues a VALU instruction every ~6.2 cycles instead of every 4: the second wave per SIMD can only come from another
- * solve.  The grid is run a's workgroups, then run b's (b.nblk == 0: none), then one finish workgroup per PENDING run
- * (n_prev <= 2: the previous launch's runs) -- fast uniform rollouts in one-wave workgroups only.  The run's arguments
- * are picked by a workgroup-uniform index into the kernel argument block (scalar loads, one copy of the body). */
-struct PairArgs { RunArgs run[2]; FinishArgs prev[2]; };
+/* Several runs in ONE launch (mpc_hip_set_pipeline level 2..MPC_GROUP_MAX).  A 65,536-candidate set is one wave per
+ * SIMD, and a lone wave issues a VALU instruction every ~6.2 cycles instead of every 4: the second wave per SIMD can only
+ * come from another solve -- and every launch of a stream pays ~10 us that do not depend on the work (the boundary between
+ * dependent dispatches, the workgroups' prologue, the tail), which a launch of four solves pays once instead of twice.
+ * The grid is run 0's workgroups, then run 1's, ... (end[w] = one past run w's last workgroup; an unused run has none),
+ * then one finish workgroup per PENDING run (the previous launch's runs) -- fast uniform rollouts in one-wave workgroups
+ * only.  The run's arguments are picked by a workgroup-uniform index into the kernel argument block (scalar loads, one
+ * copy of the body). */
+struct GroupArgs { RunArgs run[MPC_GROUP_MAX]; FinishArgs prev[MPC_GROUP_MAX]; uint32_t end[MPC_GROUP_MAX]; };
 
 template <bool SEEDED>
-__global__ __launch_bounds__(256) void rollout_pair_kernel(const DevProblem *__restrict__ probs, const PairArgs A)
+__global__ __launch_bounds__(256) void rollout_group_kernel(const DevProblem *__restrict__ probs, const GroupArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const uint32_t na = A.run[0].nblk, nr = na + A.run[1].nblk;
+    const uint32_t nr = A.end[MPC_GROUP_MAX - 1];
     if (blockIdx.x >= nr) {
+        /* (the finish workgroups FIRST in the grid instead: 1 % slower -- measured, round 3) */
         uint64_t *s_list = (uint64_t *)(lds + MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE) + 12;
         finish_body<SEEDED, 16>(A.prev[blockIdx.x - nr], blockIdx.y, lds, s_list, s_list + LIST_CAP);
         return;
     }
-    const uint32_t w = blockIdx.x >= na ? 1u : 0u;
+    const uint32_t bx = blockIdx.x;
+    uint32_t w = 0;
+#pragma unroll
+    for (uint32_t q = 0; q + 1 < MPC_GROUP_MAX; q++) w += bx >= A.end[q] ? 1u : 0u;      /* workgroup-uniform */
     const RunArgs &R = A.run[w];
     /* (seeded sets generate their controls level by level here: PREGEN's 20 KB of LDS per workgroup would not let
      * eight workgroups share a CU) */
     rollout_body<MPC_PREC_FAST, SEEDED, true, false>(probs, R.rud, R.thr, R.first, R.count, R.selection, R.rel, R.cost_last, R.cost_cum,
-                                                      R.keys, R.snap, R.snap_depth, R.snap_shift, R.pkey, R.pord, R.pcnt, blockIdx.x - (w ? na : 0u),
-                                                      R.nblk, lds);
+                                                      R.keys, R.snap, R.snap_depth, R.snap_shift, R.pkey, R.pord, R.pcnt,
+                                                      bx - (w ? A.end[w - 1] : 0u), R.nblk, lds);
 }
 
 /* multi-GPU: lexicographic (score bits, global ordinal) minimum over the gathered per-shard winners */

@@ -256,13 +256,25 @@ __device__ inline double fma3(double a, double b, double c)
     return d;
 }
 
+/* The same with the addend in SCALAR registers: for a Horner step whose addend is a compile-time constant.  fma3 makes
+ * hipcc materialise the constant in a VGPR pair with two v_mov_b32 per step -- THREE vector instructions per step, one
+ * more than the compiler's own mov + fmac; a 64-bit literal cannot be encoded in VOP3, but one SGPR-pair source can, and
+ * s_mov_b32 issues on the scalar unit beside the other waves' vector instructions: ONE vector instruction per step.
+ * Same operation, same operands: the bits are fma3's. */
+__device__ inline double fma3c(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
 /* LEAN chooses between the two spellings of a Horner step: the compiler's (mov + fmac) or fma3.  While config 2 ran one
  * wave per SIMD the compiler's was faster there (36.1 us vs 36.7 us with fma3) and fma3 only where the SIMDs were full
  * (4 M candidates: -2 %, tree expansion: -3 %); now that a stream of solves runs two waves per SIMD, every device
  * kernel uses the lean one (MPC_FAST_LEAN in mpc_kernels.h) -- one spelling, so that a candidate's cost does not depend
  * on the size of the set it came in. */
 template <bool LEAN>
-__device__ inline double horner(double p, double x, double c) { return LEAN ? fma3(p, x, c) : fma(p, x, c); }
+__device__ inline double horner(double p, double x, double c) { return LEAN ? fma3c(p, x, c) : fma(p, x, c); }   /* c: always a literal */
 
 /* exp(x) for the distance term, x >= 0: x = n ln2 + r, |r| <= ln2/2, Taylor to r^11 (3e-15 relative), scaled by 2^n.
  * ldexp overflows to +inf like exp does (exp(5000) = inf keeps "no finite score" what it is); NaN stays NaN.
@@ -274,14 +286,14 @@ __device__ inline double fast_exp_nonneg(double x)
     double r = fma(n, -6.93147180559945286227e-01, x);     /* RN(ln 2) */
     r = fma(n, -2.31904681384629955842e-17, r);            /* ln 2 - RN(ln 2) */
     double p = 1.0 / 39916800.0;
-    p = fma3(p, r, 1.0 / 3628800.0);
-    p = fma3(p, r, 1.0 / 362880.0);
-    p = fma3(p, r, 1.0 / 40320.0);
-    p = fma3(p, r, 1.0 / 5040.0);
-    p = fma3(p, r, 1.0 / 720.0);
-    p = fma3(p, r, 1.0 / 120.0);
-    p = fma3(p, r, 1.0 / 24.0);
-    p = fma3(p, r, 1.0 / 6.0);
+    p = fma3c(p, r, 1.0 / 3628800.0);
+    p = fma3c(p, r, 1.0 / 362880.0);
+    p = fma3c(p, r, 1.0 / 40320.0);
+    p = fma3c(p, r, 1.0 / 5040.0);
+    p = fma3c(p, r, 1.0 / 720.0);
+    p = fma3c(p, r, 1.0 / 120.0);
+    p = fma3c(p, r, 1.0 / 24.0);
+    p = fma3c(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);

@@ -41,12 +41,12 @@ def test_default_line_has_the_contract_keys():
     assert d["value"] > 1e11                                       # north_star's floor on one MI355X
     assert d["p50_solve_latency_ms"] < 5.0                         # ... and its latency bound
     assert d["config"]["deferred_finish"] is True
-    # the default stream of config-2 solves: two per rollout launch, and the roofline counts a launch as two solves
-    assert d["config"]["pipeline_level"] == 2 and d["config"]["solves_per_launch"] == 2
-    assert r["kernel"] == "rollout_pair_kernel" and r["solves_per_launch"] == 2
-    assert r["algorithmic_flop_per_launch"] == 2 * 65536 * 20 * (54 * 20 + 21)
-    # the kernel's time (HIP events on the dispatches) accounts for the region: 20 launches of two solves
-    assert 0.85 * d["ms_per_step"] <= d["rollout_kernel_ms"] / 2 <= 1.05 * d["ms_per_step"]
+    # the default stream of config-2 solves: four per rollout launch, and the roofline counts a launch as four solves
+    assert d["config"]["pipeline_level"] == 4 and d["config"]["solves_per_launch"] == 4
+    assert r["kernel"] == "rollout_group_kernel" and r["solves_per_launch"] == 4
+    assert r["algorithmic_flop_per_launch"] == 4 * 65536 * 20 * (54 * 20 + 21)
+    # the kernel's time (HIP events on the dispatches) accounts for the region: 10 launches of four solves
+    assert 0.85 * d["ms_per_step"] <= d["rollout_kernel_ms"] / 4 <= 1.05 * d["ms_per_step"]
     # a stream of DISTINCT solves: four candidate sets in turn, the CPU baseline checks the GPU's choice for every one
     assert d["config"]["distinct_candidate_sets"] == 4 and len(d["chosen"]["per_set"]) == 4
     assert len({c["ordinal"] for c in d["chosen"]["per_set"]}) == 4
@@ -66,10 +66,12 @@ def test_default_line_has_the_contract_keys():
     assert t["scenarios"]["lrl_semicircle"]["depth"]["4"]["first_control"] == [-0.0625, 1.0]     # SURVEY.md 8c's probe of the reference
 
 
-def test_an_odd_region_runs_one_solve_per_launch():
+def test_a_region_that_is_no_whole_number_of_launches_takes_a_smaller_group():
     d = _bench("--steps", "41", "--warmup", "5", "--no-cpu-baseline", "--no-tree")
     assert d["config"]["pipeline_level"] == 1 and d["config"]["solves_per_launch"] == 1
     assert d["roofline"]["kernel"] == "rollout_kernel" and d["roofline"]["algorithmic_flop_per_launch"] == 65536 * 20 * (54 * 20 + 21)
+    d = _bench("--steps", "42", "--warmup", "5", "--no-cpu-baseline", "--no-tree")       # 42 = 14 x 3
+    assert d["config"]["pipeline_level"] == 3 and d["config"]["solves_per_launch"] == 3 and d["roofline"]["kernel"] == "rollout_group_kernel"
 
 
 def test_two_kernel_form_and_rccl_rehearsal_choose_the_same_control():

@@ -197,7 +197,7 @@ def test_misuse_of_the_stream_and_multi_gpu_entry_points_is_refused():
     s = M.Solver(0)
     try:
         with pytest.raises(M.MpcError):
-            s.set_pipeline(3)
+            s.set_pipeline(5)
         p = W.config2_problem(depth=6)
         s.upload([p, p], [1, 2])
         buf = torch.zeros(4096, dtype=torch.int64, device="cuda")

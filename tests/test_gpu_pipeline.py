@@ -81,7 +81,7 @@ def test_deferred_finish_changes_no_result(plan):
     solver = M.Solver(0)
     try:
         want = _stream_of_solves(solver, False, plan)
-        for level in (1, 2):                                  # 1: deferred finish; 2: two runs per launch as well
+        for level in (1, 2, 3, 4):                            # 1: deferred finish; K >= 2: K runs per launch as well
             got = _stream_of_solves(solver, level, plan)
             assert len(got) == len(want)
             for a, b in zip(got, want):
@@ -102,7 +102,7 @@ def test_random_streams_give_the_same_results_at_every_pipeline_level(seed):
     solver = M.Solver(0)
     try:
         want = _stream_of_solves(solver, 0, plan)
-        for level in (1, 2):
+        for level in (1, 2, 3, 4):
             got = _stream_of_solves(solver, level, plan)
             assert len(got) == len(want)
             for a, b in zip(got, want):
@@ -116,7 +116,7 @@ def test_deferred_finish_on_a_fleet_and_with_timing():
     try:
         probs, seeds = W.fleet_problems(24, depth=10)
         out = []
-        for pipeline in (0, 1, 2):
+        for pipeline in (0, 1, 2, 3, 4):
             solver.set_pipeline(pipeline)
             solver.set_timing(1)
             solver.upload(probs, seeds)
@@ -124,16 +124,17 @@ def test_deferred_finish_on_a_fleet_and_with_timing():
             for k in range(4):
                 solver.run_seeded(0, 1024 + 64 * k, M.PREC_FAST)
             runs, k_ms, t_ms = solver.timing(reset=True)
-            assert runs == (2 if pipeline == 2 else 4) and 0 < k_ms <= t_ms       # level 2: one pair of events per launch of two runs
+            # level K >= 2: one pair of events per launch of K runs (4 runs: two launches at K = 2 and K = 3, one at K = 4)
+            assert runs == {0: 4, 1: 4, 2: 2, 3: 2, 4: 1}[pipeline] and 0 < k_ms <= t_ms
             res = solver.fetch()
             out.append([(r.status, r.best_ordinal, r.best_last, traj_array(r).tobytes()) for r in res])
-        assert out[0] == out[1] == out[2]
+        assert out[0] == out[1] == out[2] == out[3] == out[4]
         solver.set_timing(1)
     finally:
         solver.close()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4])
 def test_winner_record_sink_carries_the_winners_controls(pipeline):
     """mpc_hip_set_winner_record_sink / mpc_hip_copy_winner_records: (score bits, ordinal) as the plain sink writes
     them, then the winner's clamped controls per level -- the ones in the fetched trajectory, bit for bit -- for every
@@ -180,7 +181,7 @@ def test_winner_record_sink_carries_the_winners_controls(pipeline):
         solver.close()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4])
 def test_a_control_buffer_rewritten_between_runs_needs_a_flush_first(pipeline):
     """include/mpc_hip.h, the deferred finish: a run's explicit control arrays are still read by its PENDING finish (the
     strict decision among near-ties, the winner's trajectory and record), so a sampling loop that rewrites ONE control
