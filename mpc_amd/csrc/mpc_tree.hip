@@ -39,7 +39,10 @@ __device__ inline void control_pick(const DevProblem &P, double last_r, double l
     const bool t3 = P.maxt > high_t + tol;
     const bool t4 = fabs(P.mint - last_t) > tol && fabs(P.maxt - last_t) > tol;
     const uint32_t nr = 3u + r3 + r4 + r5;
-    const uint32_t ti = j / nr, ri = j - ti * nr;
+    /* j / nr without the ~20-instruction integer division: nr is 3..6 and j < 30, where floor(j * ceil(2^16 / nr) / 2^16)
+     * is exact (the excess j * (ceil - 2^16 / nr) / 2^16 < 30 / 65536 never reaches the next multiple of 1 / nr) */
+    const uint32_t inv = nr == 3u ? 21846u : (nr == 4u ? 16384u : (nr == 5u ? 13108u : 10923u));
+    const uint32_t ti = (j * inv) >> 16, ri = j - ti * nr;
     r = ri == 0 ? P.minr : (ri == 1 ? P.midr : P.maxr);
     int k = (int)ri - 3;                                   /* k-th of the optional rudders that are present */
     if (r3) { if (k == 0) r = low_r; k--; }
@@ -238,10 +241,16 @@ __device__ inline uint32_t find_parent(const uint32_t *offset, uint32_t n_parent
 
 __device__ inline uint32_t window_parent(const uint32_t *win, uint32_t par0, uint32_t n_parent, uint32_t c, uint32_t &first)
 {
-    uint32_t lo = 0, hi = min((uint32_t)PARENT_WINDOW - 1, n_parent - par0);          /* win[lo] <= c < win[hi] */
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (win[mid] <= c) lo = mid; else hi = mid;
+    /* win[0] <= c < win[hi]; the window has PARENT_WINDOW = 64 entries, so SIX halvings always suffice: a fixed trip count
+     * (no data-dependent loop: hipcc turns `while (hi - lo > 1)` into an exec-masked loop with a branch and a full LDS
+     * wait per trip), every step one LDS read and two selects; steps past convergence re-read win[lo] and change nothing */
+    uint32_t lo = 0, hi = min((uint32_t)PARENT_WINDOW - 1, n_parent - par0);
+#pragma unroll
+    for (int step = 0; step < 6; step++) {
+        const uint32_t mid = (lo + hi) >> 1;              /* == lo once hi - lo <= 1 */
+        const bool le = win[mid] <= c;
+        lo = le ? mid : lo;
+        hi = le ? hi : max(mid, lo + 1);                  /* never collapses the interval below one entry */
     }
     first = win[lo];
     return par0 + lo;
