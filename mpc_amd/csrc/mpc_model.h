@@ -443,6 +443,31 @@ __device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double
     s.rpm = fma(z.sgn, z.m, c.target_rpm);
 }
 
+/* |atan2(y, x)| in [0, pi] for the heading term, in FP32 like the atan2f it replaces (the term's accuracy is FP32's
+ * either way: ~1e-7 relative, tools/fp32_error.py) but without what the library function carries for arguments this
+ * caller never passes -- infinities, NaN tests, a frexp/ldexp-scaled division: min/max, one v_rcp_f32, a degree-7
+ * minimax polynomial in t^2 for atan(t) / t on [0, 1] (1.7e-8 relative in exact arithmetic, 1.5 ulp evaluated in FP32;
+ * fitted by tools/fit_atan.py), two selects.  ~24 instructions instead of ~40.  (0, 0) gives 0 like atan2f. */
+__device__ inline float fast_abs_atan2f(float y, float x)
+{
+    const float ay = fabsf(y), ax = fabsf(x);
+    const float mx = fmaxf(fmaxf(ax, ay), 1.0e-37f), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = t * t;
+    float p = 2.922662999e-03f;
+    p = fmaf(p, s, -1.637326181e-02f);
+    p = fmaf(p, s, 4.321546480e-02f);
+    p = fmaf(p, s, -7.551984489e-02f);
+    p = fmaf(p, s, 1.066557691e-01f);
+    p = fmaf(p, s, -1.421084106e-01f);
+    p = fmaf(p, s, 1.999372840e-01f);
+    p = fmaf(p, s, -3.333314955e-01f);
+    float a = fmaf(t, s * p, t);
+    a = ay > ax ? 1.57079637f - a : a;
+    a = x < 0.0f ? 3.14159274f - a : a;
+    return a;
+}
+
 /* tracking cost from the fast state; q_last = the schedule row of the level's last substep */
 template <bool LEAN = false>
 __device__ inline double fast_score(const double *cp, const FastVeh &s, const Weights &w, const double *q_last)
@@ -454,7 +479,11 @@ __device__ inline double fast_score(const double *cp, const FastVeh &s, const We
     /* |headingDifference(ref, cmg)| = |angle between the travel direction and the reference heading| */
     const double cross = dx * cp[5] - dy * cp[4];
     const double dot = fma(dy, cp[5], dx * cp[4]);
+#ifdef MPC_LIBRARY_ATAN2F
     const double heading_diff = (double)fabsf(atan2f((float)cross, (float)dot));
+#else
+    const double heading_diff = (double)fast_abs_atan2f((float)cross, (float)dot);
+#endif
     const double sog = fast_sqrt(fma(gdx, gdx, gdy * gdy)) * q_last[5];
     const double speed_diff = fabs(cp[3] - sog);
     const double ex = cp[6] - s.x, ey = cp[7] - s.y;
