@@ -154,18 +154,18 @@ def measured_valu(k1_seconds, spl=1):
     rate 256 CU x 4 SIMD x 16 lanes x 2.4 GHz).  The instruction count comes from the committed PMC pass of this
     command (counters cannot be read inside the timed process), the time is this run's."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
         scale = spl / float(prof.get("solves_per_launch", 1))       # the profile's launch may hold another number of solves
         insts = float(prof["sq_insts_valu"]) * scale
     except Exception:
         return None
     out = {"sq_insts_valu_per_launch": insts, "lane_issue_frac": insts * 64 / (k1_seconds * 256 * 4 * 16 * 2.4e9),
-           "source": "profiles/r02_pmc_summary.json (SQ_INSTS_VALU) / this run's kernel time"}
+           "source": "profiles/r03_pmc_summary.json (SQ_INSTS_VALU) / this run's kernel time"}
     try:        # hardware-counted FP64 operations (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 lanes, FMA = 2 FLOP)
         rows = {ln.split("|")[0].strip(): float(ln.split("|")[5])
-                for ln in open(os.path.join(ROOT, "profiles", "r02_fp64_flop_counters.txt")) if ln.startswith("config2")}
-        # "config2_pair": counted on the two-solve launch itself; "config2": on a one-solve launch
-        flop = rows["config2_pair"] if spl == 2 and "config2_pair" in rows else rows["config2"] * spl
+                for ln in open(os.path.join(ROOT, "profiles", "r03_fp64_flop_counters.txt")) if ln.startswith("config2")}
+        # "config2_group": counted on the four-solve launch itself; "config2": on a one-solve launch
+        flop = rows["config2_group"] * spl / 4.0 if spl >= 2 and "config2_group" in rows else rows["config2"] * spl
         out["counted_fp64_flop_per_launch"] = flop
         out["counted_fp64_tflops"] = flop / k1_seconds / 1e12
         out["counted_fp64_frac_of_peak"] = flop / k1_seconds / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
@@ -177,7 +177,7 @@ def measured_valu(k1_seconds, spl=1):
 def measured_traffic(spl=1):
     """HBM bytes per rollout-kernel launch from the committed PMC profile of this same command (rocprofv3 --pmc
     cannot run inside the timed process); None if no profile has been committed."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
     try:
         prof = json.load(open(path))
         return int(prof["hbm_bytes_per_launch"] * spl / float(prof.get("solves_per_launch", 1)))
@@ -502,7 +502,7 @@ def main():
                 "kernel": "rollout_group_kernel" if spl >= 2 else "rollout_kernel", "solves_per_launch": spl, "achieved": flop / (k1_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flop / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": measured_traffic(spl) if args.workload == "config2" and prec == M.PREC_FAST else None,
-                "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+                "traffic_source": "profiles/r03_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                 "measured_valu": measured_valu(k1_ms * 1e-3, spl) if args.workload == "config2" and prec == M.PREC_FAST else None,
                 "algorithmic_flop_per_launch": flop, "kernel_steps_per_sec": spl * steps_per_solve / (k1_ms * 1e-3),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,

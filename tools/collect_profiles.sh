@@ -7,7 +7,7 @@ set -e
 D=gpurun_out/${1:-prof}
 mkdir -p "$D"
 export TMPDIR=/tmp
-PMC_ARGS="--steps 20 --warmup 5 --ramp-seconds 0 --no-cpu-baseline"
+PMC_ARGS="--steps 20 --warmup 5 --ramp-seconds 0 --no-cpu-baseline --no-tree"
 
 # kernel trace of the default bench command (the numbers roofline.achieved is checked against)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o r1 -- python3 bench.py > "$D/bench_prof.log" 2> "$D/bench_prof.err"

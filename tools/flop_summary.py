@@ -31,13 +31,13 @@ def k1_avg_ns(stats_csv, kernel="rollout_kernel"):
 
 print("# rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 (wave-instructions, mean per launch of rollout_kernel) x 64 lanes,")
 print("# FMA counted as 2 FLOP; duration = rocprofv3 --kernel-trace average of the same workload; peak 78.6 TFLOP/s FP64 vector")
-print("# config2 = one solve per launch (rollout_kernel), config2_pair = two solves per launch (rollout_pair_kernel)")
+print("# config2 = one solve per launch (rollout_kernel), config2_group = four solves per launch (rollout_group_kernel)")
 print("# workload | fma | mul | add | trans | FP64 FLOP per launch | K1 avg us | achieved TFLOP/s | fraction of peak")
-# config2: bench.py's timed region launches rollout_pair_kernel (two solves per launch, pipeline level 2), its latency
+# config2: bench.py's timed region launches rollout_group_kernel (four solves per launch, pipeline level 4), its latency
 # loop rollout_kernel (one solve per launch)
 c2 = os.path.join(root, "profiles", tag + "_bench_kernel_stats.csv")
 for w, d, stats, kernel in (("config2", "config2", c2, "rollout_kernel"),
-                            ("config2_pair", "config2", c2, "rollout_pair_kernel"),
+                            ("config2_group", "config2", c2, "rollout_group_kernel"),
                             ("config4", "config4", os.path.join(src, "config4", "stats", "k_kernel_stats.csv"), "rollout_kernel"),
                             ("config5", "config5", os.path.join(src, "config5", "stats", "k_kernel_stats.csv"), "rollout_kernel")):
     c = counters(os.path.join(src, d, "flops"), kernel)
