@@ -308,6 +308,9 @@ void mpc_pack_problem(const mpc_problem *p, uint64_t seed, const Model &model, D
     d->head_uniform = p->n_substeps >= 2; d->pad0 = 0; d->pad1 = 0;
     for (int s = 1; s + 1 < p->n_substeps; s++)
         if (p->substeps[s] != p->substeps[0]) d->head_uniform = 0;
+    /* 2: ... and the last substep is a negligible remainder (the 1.4e-16 s that VehicleState.h:49-53's floating-point loop
+     * leaves of a 1-s level): the fast model forms its displacement and leaves the state alone (mpc_model.h) */
+    if (d->head_uniform && p->substeps[p->n_substeps - 1] <= p->substeps[0] * 0x1p-40) d->head_uniform = 2;
     double level_time = 0;
     for (int s = 0; s < p->n_substeps; s++) level_time += p->substeps[s];
     for (int l = 0; l < p->depth; l++) {

@@ -25,7 +25,8 @@ struct DevProblem {
     double gr, gt, minr, midr, maxr, mint, maxt, tol;
     uint64_t seed;
     int32_t depth, nsub;
-    int32_t head_uniform;        /* substeps 0 .. nsub-2 equally long (nsub >= 2): every schedule simulate() itself makes */
+    int32_t head_uniform;        /* 1: substeps 0 .. nsub-2 equally long (nsub >= 2): every schedule simulate() itself makes;
+                                  * 2: ... and the last one a negligible remainder (< 2^-40 of the others) */
     int32_t pad0; double pad1;   /* keeps cp 16-byte aligned for the staging vectors */
     mpc::Model model;            /* this problem's hull (mpc_hip_set_model; VehicleState.h:86-101) */
     double cp[MPC_MAX_DEPTH * CP_STRIDE];

@@ -234,7 +234,7 @@ __device__ inline double fast_level_and_score(const DevProblem &P, const Model &
 #define MPC_FAST_LEAN true
 #endif
     if (UNIFORM) fast_level<0, MPC_FAST_LEAN>(s, r, t, row0, P.nsub, M);
-    else if (P.head_uniform) fast_level_head_uniform<MPC_FAST_LEAN>(s, r, t, subL, P.nsub, M);
+    else if (P.head_uniform) fast_level_head_uniform<MPC_FAST_LEAN>(s, r, t, subL, P.nsub, M, P.head_uniform == 2);
     else fast_level<SUB_STRIDE, MPC_FAST_LEAN>(s, r, t, subL, P.nsub, M);
     return fast_score<MPC_FAST_LEAN>(cp, s, w, q_last);
 }

@@ -420,9 +420,15 @@ __device__ inline void fast_level(FastVeh &s, double rudder, double throttle, co
 /* Substeps 0 .. n_sub-2 equally long, the last one not (n_sub >= 2): what VehicleState::simulate itself produces
  * (:48-54: steps of 0.1 s and a remainder; the 1-s level of controller.cpp:149 is ten of 0.1 s and one of 1.4e-16 s).
  * The head runs like a uniform level (schedule row in registers, position in units of dt), the tail as one plain substep. */
+/* tail_negligible (wave-uniform; the host sets it when the last substep is shorter than 2^-40 of the others, as the
+ * 1.4e-16-s remainder of the reference's 1-s level is): such a substep moves the rpm by 1e-13, the speed, heading and
+ * position by < 1e-15 of themselves -- ten orders below this model's tolerance -- so the state is left as it is and only
+ * what the cost reads of that substep is formed: its displacement delta = v * dl, from which course made good and speed
+ * over ground follow (VehicleState.h:139-144 -- the reference's cmg / sog ARE those of this last tiny step).  One
+ * substep in eleven less for every child of the reference-native tree. */
 template <bool LEAN = false>
 __device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double throttle, const double *sub, int n_sub,
-                                               const Model &M)
+                                               const Model &M, bool tail_negligible)
 {
     const FastLevelCoef c = fast_level_coef<LEAN>(rudder, throttle, M);
     FastSlew z = fast_slew_begin(s.rpm, c.target_rpm, M.c_prop);
@@ -437,8 +443,9 @@ __device__ inline void fast_level_head_uniform(FastVeh &s, double rudder, double
     s.x = xs * dt; s.y = ys * dt;
     const double *q = sub + (n_sub - 1) * SUB_STRIDE;
     const double dl = q[0];
-    fast_substep<false>(z.m, s.v, s.sh, s.ch, s.x, s.y, z.sc, z.pst, q[1], c.kpc * q[2], M.drag_coefficient * q[2],
-                        c.kyaw * dl, dl);
+    if (!tail_negligible)
+        fast_substep<false>(z.m, s.v, s.sh, s.ch, s.x, s.y, z.sc, z.pst, q[1], c.kpc * q[2], M.drag_coefficient * q[2],
+                            c.kyaw * dl, dl);
     s.delta = s.v * dl;
     s.rpm = fma(z.sgn, z.m, c.target_rpm);
 }

@@ -355,7 +355,7 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
     ch.s.x = A.x[par]; ch.s.y = A.y[par]; ch.s.sh = A.h[par]; ch.s.ch = A.cmg[par]; ch.s.v = A.v[par]; ch.s.rpm = A.rpm[par];
     ch.s.delta = 0;
     const Model M = P.model;
-    if (P.head_uniform) fast_level_head_uniform<true>(ch.s, ch.r, ch.t, subL, P.nsub, M);      /* the reference's own 1-s level */
+    if (P.head_uniform) fast_level_head_uniform<true>(ch.s, ch.r, ch.t, subL, P.nsub, M, P.head_uniform == 2);      /* the reference's own 1-s level */
     else fast_level<SUB_STRIDE, true>(ch.s, ch.r, ch.t, subL, P.nsub, M);
     const Weights w{P.wd, P.wh, P.ws};
     ch.score = fast_score<true>(cpL + level * CP_STRIDE, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
