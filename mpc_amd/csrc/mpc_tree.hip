@@ -190,9 +190,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *
 /* ---- expansion: one lane per child ------------------------------------------------------------------------ */
 struct Child { Veh s; double r, t, score, cum; uint32_t parent; };
 
-/* child c of the level whose parents are A: j-th control pair (throttle outer, rudder inner) of parent `par` */
+__device__ inline void tree_bound_update(uint64_t *bound, uint64_t k, const DevProblem &P, double rel);
+__device__ inline double tree_bound_read(const uint64_t *bound);
+
+/* child c of the level whose parents are A: j-th control pair (throttle outer, rudder inner) of parent `par`.
+ * PRUNE / dmax2: as make_child_fast below -- a wave all of whose leaves are too far from the checkpoint to be the level's
+ * winner (or its runner-up within the libm_tie window) skips compareStates and reports +inf. */
+template <bool PRUNE = false>
 __device__ inline Child make_child(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
-                                   uint32_t par, uint32_t j, int level)
+                                   uint32_t par, uint32_t j, int level, double dmax2 = 0.0)
 {
     double r, t;
     control_pick(P, A.last_r[par], A.last_t[par], j, r, t);
@@ -201,7 +207,14 @@ __device__ inline Child make_child(const DevProblem &P, const double *cpL, const
     const Model M = P.model;                                                          /* wave-uniform: scalar registers */
     strict_level(ch.s, r, t, subL, P.nsub, P.cx, P.cy, M);                              /* controller.cpp:149-150 */
     const Weights w{P.wd, P.wh, P.ws};
-    ch.score = strict_score(cpL + level * CP_STRIDE, ch.s, w);                        /* :155 */
+    const double *cp = cpL + level * CP_STRIDE;
+    bool skip = false;
+    if (PRUNE) {
+        const double dx = cp[0] - ch.s.x, dy = cp[1] - ch.s.y;
+        const bool far = dx * dx + dy * dy >= dmax2;
+        skip = __builtin_amdgcn_ballot_w64(!far) == 0;
+    }
+    ch.score = skip ? __longlong_as_double((long long)KEY_INF) : strict_score(cp, ch.s, w);   /* :155 */
     ch.cum = A.cum[par] + ch.score;                                                   /* :156 */
     ch.r = r; ch.t = t; ch.parent = par;                                              /* :152-153 (unclamped) */
     return ch;
@@ -262,7 +275,8 @@ template <bool STORE>
 __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                      const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
                                                      uint32_t tpb, uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
-                                                     uint64_t *__restrict__ pkey2, const uint64_t *__restrict__ meta_parent)
+                                                     uint64_t *__restrict__ pkey2, const uint64_t *__restrict__ meta_parent,
+                                                     uint64_t *bound)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
@@ -289,10 +303,11 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
             if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[min(par_next + threadIdx.x, n_parent)];
         }
         const uint32_t c = tile * 256 + threadIdx.x;
+        const double dmax2 = STORE ? 0.0 : tree_bound_read(bound);     /* requested now, used after the substeps */
         if (c < n_child) {
             uint32_t first;
             const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
-            const Child ch = make_child(P, cpL, subL, A, par, c - first, level);
+            const Child ch = make_child<!STORE>(P, cpL, subL, A, par, c - first, level, dmax2);
             if (STORE) store_child(B, c, ch);
             const uint64_t kc = key_of(ch.score);
             if (kc < k) { second = k; k = kc; o = c; }                /* (a lane's children come in ascending order: ties keep the first) */
@@ -306,7 +321,11 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     }
     const uint64_t my_k = k, my_o = o;
     block_argmin(k, o, red);
-    if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; red[8] = o; }
+    if (threadIdx.x == 0) {
+        pkey[blockIdx.x] = k; pord[blockIdx.x] = o; red[8] = o;
+        /* strict expansion: the window that must stay unpruned is libm_tie's (1e-12); 1e-9 leaves six orders of margin */
+        if (!STORE) tree_bound_update(bound, k, P, 1.0e-9);
+    }
     __syncthreads();
     /* the workgroup's runner-up key (mpc_tree_level.libm_tie): every lane offers its best, the winner's lane its next best */
     uint64_t ru = (my_o == red[8]) ? second : my_k, zero = 0;
@@ -347,8 +366,15 @@ __global__ __launch_bounds__(64) void leaf_record_kernel(const DevProblem *__res
  * and scores are the strict path's -- bit for bit what the strict expansion returns for the same leaf. */
 struct FastChild { FastVeh s; double r, t, score, cum; uint32_t parent; };
 
+/* dmax2 (PRUNE): a leaf whose squared distance to its checkpoint is at least dmax2 cannot be the level's winner nor lie
+ * inside its refine window, whatever its heading and speed terms are (all three terms of controller.cpp:240 are >= 0, so
+ * score >= w_d exp(distance)): when that holds for EVERY leaf of a wave, the wave skips the cost -- atan2, two square roots,
+ * exp: ~100 of ~600 instructions per leaf -- and reports +inf.  The bound only ever comes from scores already computed
+ * (tree_bound_update below), so which leaves are skipped depends on timing, but no result does: the level's minimum, its
+ * first holder and its near-tie set are the same with any bound, including none. */
+template <bool PRUNE = false>
 __device__ inline FastChild make_child_fast(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
-                                            uint32_t par, uint32_t j, int level)
+                                            uint32_t par, uint32_t j, int level, double dmax2 = 0.0)
 {
     FastChild ch;
     control_pick(P, A.last_r[par], A.last_t[par], j, ch.r, ch.t);
@@ -358,10 +384,38 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
     if (P.head_uniform) fast_level_head_uniform<true>(ch.s, ch.r, ch.t, subL, P.nsub, M, P.head_uniform == 2);      /* the reference's own 1-s level */
     else fast_level<SUB_STRIDE, true>(ch.s, ch.r, ch.t, subL, P.nsub, M);
     const Weights w{P.wd, P.wh, P.ws};
-    ch.score = fast_score<true>(cpL + level * CP_STRIDE, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
+    const double *cp = cpL + level * CP_STRIDE;
+    bool skip = false;
+    if (PRUNE) {
+        const double ex = cp[6] - ch.s.x, ey = cp[7] - ch.s.y;
+        const bool far = fma(ex, ex, ey * ey) >= dmax2;                /* false for a NaN state and for "no bound yet" (NaN) */
+        skip = __builtin_amdgcn_ballot_w64(!far) == 0;                 /* wave-uniform: every active lane is far */
+    }
+    ch.score = skip ? __longlong_as_double((long long)KEY_INF) : fast_score<true>(cp, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
     ch.cum = A.cum[par] + ch.score;
     ch.parent = par;
     return ch;
+}
+
+/* The pruning bound of an unstored (final) level: bound[0] = the smallest score key any finished workgroup has reported,
+ * bound[1] = bits of dmax2 = (log(limit / w_d))^2 with limit = twice the refine window above that score (strict
+ * expansion: the libm_tie window, which is far narrower) -- both only ever decrease (atomicMin on the bit patterns of
+ * non-negative doubles).  Thread 0 of a workgroup, once, after its argmin. */
+__device__ inline void tree_bound_update(uint64_t *bound, uint64_t k, const DevProblem &P, double rel)
+{
+    if (k >= KEY_INF) return;
+    const uint64_t old = atomicMin((unsigned long long *)bound, (unsigned long long)k);
+    if (k >= old) return;
+    const double limit = mpc_refine_limit(__longlong_as_double((long long)k), rel, P.wd, P.wh, P.ws);
+    const double dmax = log(limit / P.wd);                             /* w_d == 0: +inf, nothing is ever far */
+    if (!(dmax >= 0.0)) return;                                        /* (a score below w_d cannot happen: exp >= 1) */
+    atomicMin((unsigned long long *)(bound + 1), (unsigned long long)__double_as_longlong(dmax * dmax));
+}
+
+/* the current bound, read past the caches (another workgroup's atomic wrote it) */
+__device__ inline double tree_bound_read(const uint64_t *bound)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(bound + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 template <bool STORE>
@@ -369,7 +423,8 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                                                           const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
                                                           double refine_rel, uint32_t tpb,
                                                           uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
-                                                          uint32_t *__restrict__ pcnt, const uint64_t *__restrict__ meta_parent)
+                                                          uint32_t *__restrict__ pcnt, const uint64_t *__restrict__ meta_parent,
+                                                          uint64_t *bound)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
@@ -400,10 +455,12 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                 if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[min(par_next + threadIdx.x, n_parent)];
             }
             const uint32_t c = tile * 256 + threadIdx.x;
+            /* the unstored (final) level: this tile's pruning bound, requested now, used after the substeps */
+            const double dmax2 = STORE ? 0.0 : tree_bound_read(bound);
             if (c < n_child) {
                 uint32_t first;
                 const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
-                const FastChild ch = make_child_fast(P, cpL, subL, A, par, c - first, level);
+                const FastChild ch = make_child_fast<!STORE>(P, cpL, subL, A, par, c - first, level, dmax2);
                 if (STORE) {
                     B.x[c] = ch.s.x; B.y[c] = ch.s.y; B.h[c] = ch.s.sh; B.cmg[c] = ch.s.ch; B.v[c] = ch.s.v; B.rpm[c] = ch.s.rpm;
                     B.sog[c] = ch.s.delta; B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.cum[c] = ch.cum; B.last_score[c] = ch.score;
@@ -433,7 +490,10 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(cnt, mine);
     __syncthreads();
-    if (threadIdx.x == 0) { pkey[blockIdx.x] = k; pord[blockIdx.x] = o; pcnt[blockIdx.x] = *cnt; }
+    if (threadIdx.x == 0) {
+        pkey[blockIdx.x] = k; pord[blockIdx.x] = o; pcnt[blockIdx.x] = *cnt;
+        if (!STORE) tree_bound_update(bound, red[8], P, 2.0 * refine_rel);
+    }
 }
 
 /* controls along the path root -> child c of the level whose parents are levels[L] (n_parent of them) */
@@ -842,7 +902,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     }
     if (now && now(now_ctx) >= end_time) blind = 0;                       /* the loop below breaks at once */
     if (!h->d_tree_meta) {
-        HIP_TRY(hipMalloc(&h->d_tree_meta, sizeof(uint64_t) * TREE_META * (MPC_MAX_DEPTH + 2)));
+        HIP_TRY(hipMalloc(&h->d_tree_meta, sizeof(uint64_t) * (TREE_META * (MPC_MAX_DEPTH + 2) + 2)));   /* + the pruning bound's two words */
         HIP_TRY(hipHostMalloc(&h->h_tree_meta, sizeof(uint64_t) * TREE_META * (MPC_MAX_DEPTH + 2)));
     }
     if (blind > 0) {
@@ -867,6 +927,9 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         HIP_TRY(hipMalloc(&h->d_bpar, sizeof(uint32_t) * 64));
         h->cap_bpar = 64;
     }
+    /* the pruning bound of the unstored final level (tree_bound_update): "none yet" = all ones (as a double: NaN) */
+    uint64_t *d_bound = h->d_tree_meta + TREE_META * (MPC_MAX_DEPTH + 2);
+    HIP_TRY(hipMemsetAsync(d_bound, 0xFF, sizeof(uint64_t) * 2, h->stream));
     hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]), (int)fast, h->d_bpar,
                        blind > 0 ? h->d_tree_meta : (uint64_t *)nullptr);
     HIP_TRY(hipGetLastError());
@@ -880,17 +943,17 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             TreeLevelBuf &A = h->tree[it], &B = h->tree[it + 1];
             if (fast) {
                 if (stored) hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                               (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp);
+                                               (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp, d_bound);
                 else hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                        (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp);
+                                        (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp, d_bound);
                 hipLaunchKernelGGL(tree_post_kernel<true>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
                                    (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_pkey2, h->d_winners, h->d_tree_meta,
                                    (int)(stored && it + 1 < blind), h->d_bpar);
             } else {
                 if (stored) hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                               (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp);
+                                               (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp, d_bound);
                 else hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                        (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp);
+                                        (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp, d_bound);
                 hipLaunchKernelGGL(tree_post_kernel<false>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
                                    0.0, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_pkey2, h->d_winners, h->d_tree_meta,
                                    (int)(stored && it + 1 < blind), h->d_bpar);
@@ -972,19 +1035,19 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         if (fast) {
             if (stored)
                 hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound);
             else
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound);
             hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
                                (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_winners);
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound);
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound);
             hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
             if (!stored)
                 hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
