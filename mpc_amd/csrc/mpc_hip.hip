@@ -320,6 +320,40 @@ void mpc_pack_problem(const mpc_problem *p, uint64_t seed, const Model &model, D
         c[4] = sin(p->checkpoints[l].heading); c[5] = cos(p->checkpoints[l].heading);
         c[6] = c[0] - p->current_x * (level_time * (l + 1)); c[7] = c[1] - p->current_y * (level_time * (l + 1));
     }
+    /* Reach of one level.  Every substep (VehicleState.h:111-148) moves the vessel by v' dt through the water, with
+     *     v' = v + dt/m (pc (ps^2 - v^2) cos(rudder angle) - D v^3),   pc, D >= 0,  0 <= cos <= 1 (|max rudder angle| <= pi/2),
+     * and the rpm never leaves [min(rpm, idle), max(rpm, max_rpm)] (it moves toward a target inside [idle, max_rpm]).  So for
+     * a level entered with 0 <= v and |rpm| <= R = max(|idle|, |max_rpm|):  v' <= v + dt pc (C R)^2 / m  (the other terms
+     * only slow a vessel moving forward), hence v <= V = v0 + T pc (C R)^2 / m throughout, and  v' >= v (1 - dt (pc v + D v^2) / m)
+     * >= 0 as long as dt_max (pc V + D V^2) / m <= 1 (asked for with 1/2).  After the substep that ends at time t the speed
+     * is at most v0 + a t (a = pc (C R)^2 / m), so the level's path, sum v' dt, is no longer than v0 T + a T (T + dt_max) / 2.
+     * The margins (1e-9 on the speed, 1e-6 on the time, and 1e-6 m where the bound is used) are orders above what rounding
+     * and the fast model's 1e-9 approximations of the same recurrence can add. */
+    {
+        const double R = fmax(fabs(model.idle_rpm), fabs(model.max_rpm));
+        const double ps = model.c_prop * R;
+        double dt_max = 0;
+        bool ok = model.prop_coefficient >= 0 && model.drag_coefficient >= 0 && model.mass > 0 &&
+                  fabs(model.max_rudder_angle) <= 1.5707963267948966 && isfinite(level_time) && p->n_substeps > 0;
+        for (int s = 0; s < p->n_substeps; s++) {
+            if (!(p->substeps[s] >= 0)) ok = false;
+            dt_max = fmax(dt_max, p->substeps[s]);
+        }
+        const double pc = model.prop_coefficient, D = model.drag_coefficient;
+        double vcap = -1.0;
+        if (ok && dt_max > 0) {
+            const double rhs = 0.5 * model.mass / dt_max;                    /* pc V + D V^2 <= rhs */
+            vcap = D > 0 ? (sqrt(pc * pc + 4.0 * D * rhs) - pc) / (2.0 * D) : (pc > 0 ? rhs / pc : 1.0e300);
+            vcap *= 1.0 - 1.0e-9;
+        }
+        d->reach_dv = level_time * pc * ps * ps / model.mass * (1.0 + 1.0e-9);
+        d->reach_t = level_time * (1.0 + 1.0e-6);
+        d->reach_acc = 0.5 * d->reach_dv * (level_time + dt_max) * (1.0 + 1.0e-6);
+        d->reach_pad = 0;
+        d->reach_vcap = ok && isfinite(d->reach_dv) && isfinite(vcap) ? vcap : -1.0;
+        d->reach_rpm = R;
+        d->reach_cx = p->current_x * level_time; d->reach_cy = p->current_y * level_time;
+    }
     for (int s = 0; s < p->n_substeps; s++) {
         double *q = d->sub + s * SUB_STRIDE;
         const double dt = p->substeps[s];

@@ -28,6 +28,11 @@ struct DevProblem {
     int32_t head_uniform;        /* 1: substeps 0 .. nsub-2 equally long (nsub >= 2): every schedule simulate() itself makes;
                                   * 2: ... and the last one a negligible remainder (< 2^-40 of the others) */
     int32_t pad0; double pad1;   /* keeps cp 16-byte aligned for the staging vectors */
+    /* How far a node can travel through the water in one level (mpc_pack_problem derives it from the hull and the schedule;
+     * the tree search's final level leaves out parents none of whose children can come near enough to win, mpc_tree.hip):
+     * a node with 0 <= v, v + reach_dv <= reach_vcap and |rpm| <= reach_rpm moves at most v * reach_t + reach_acc.
+     * reach_vcap < 0: no such bound for this hull / schedule. */
+    double reach_dv, reach_t, reach_vcap, reach_rpm, reach_cx, reach_cy, reach_acc, reach_pad;
     mpc::Model model;            /* this problem's hull (mpc_hip_set_model; VehicleState.h:86-101) */
     double cp[MPC_MAX_DEPTH * CP_STRIDE];
     double sub[MPC_MAX_SUBSTEPS * SUB_STRIDE];
@@ -60,6 +65,7 @@ struct TreeLevelBuf {
     double *x = nullptr, *y = nullptr, *h = nullptr, *v = nullptr, *rpm = nullptr, *cmg = nullptr, *sog = nullptr;
     double *last_r = nullptr, *last_t = nullptr, *cum = nullptr, *last_score = nullptr;
     uint32_t *parent = nullptr, *count = nullptr, *offset = nullptr;   /* offset has cap + 1 entries */
+    float *margin = nullptr;    /* how far beyond its reach the NEXT level's checkpoint lies from the node (node_margin, mpc_tree.hip) */
     size_t cap = 0;
     size_t n = 0;
     size_t first = 0;      /* multi-GPU shard: the level is the slice [first, first + n) of the full level */
@@ -69,6 +75,7 @@ struct TreeLevelBuf {
 struct LevelPtrs {
     double *x, *y, *h, *v, *rpm, *cmg, *sog, *last_r, *last_t, *cum, *last_score;
     uint32_t *parent, *count, *offset;
+    float *margin;
 };
 
 /* The near-tie window above a minimum score m: everything up to m (1 + rel) -- but never narrower than rel x 1 % of the

@@ -75,7 +75,7 @@ static LevelPtrs ptrs(const TreeLevelBuf &b)
 {
     const size_t f = b.first;       /* a sliced level looks like a whole one to the kernels */
     return LevelPtrs{b.x + f, b.y + f, b.h + f, b.v + f, b.rpm + f, b.cmg + f, b.sog + f, b.last_r + f, b.last_t + f,
-                     b.cum + f, b.last_score + f, b.parent + f, b.count + f, b.offset + f};
+                     b.cum + f, b.last_score + f, b.parent + f, b.count + f, b.offset + f, b.margin + f};
 }
 
 /* Node records.  strict: x y h v rpm cmg sog.  fast (MPC_PREC_FAST): x, y through the water, h = sin(heading),
@@ -90,7 +90,7 @@ __global__ void root_kernel(const DevProblem *__restrict__ probs, LevelPtrs L, i
     const DevProblem &P = probs[0];
     L.x[0] = P.sx; L.y[0] = P.sy; L.h[0] = fast ? sin(P.sh) : P.sh; L.v[0] = P.sv; L.rpm[0] = P.srpm;
     L.cmg[0] = fast ? cos(P.sh) : 0; L.sog[0] = 0; L.last_r[0] = P.last_r; L.last_t[0] = P.last_t; L.cum[0] = 0; L.last_score[0] = 0;
-    L.parent[0] = 0;
+    L.parent[0] = 0; L.margin[0] = 0.0f;
     if (meta) {
         const uint32_t c = control_count(P, P.last_r, P.last_t);
         L.count[0] = c; L.offset[0] = 0; L.offset[1] = c; bpar[0] = 0;
@@ -192,26 +192,59 @@ struct Child { Veh s; double r, t, score, cum; uint32_t parent; };
 
 __device__ inline void tree_bound_update(uint64_t *bound, uint64_t k, const DevProblem &P, double rel);
 __device__ inline double tree_bound_read(const uint64_t *bound);
+__device__ inline uint64_t tree_bound_key(const uint64_t *bound);
+__device__ inline void tree_bound_offer(uint64_t *bound, uint64_t seen, uint64_t kc, const DevProblem &P, double rel);
+
+/* What a stored node keeps for the expansion of its children, should that be the search's final level: by how much the
+ * NEXT level's checkpoint lies beyond what the node can travel in one level (DevProblem.reach_*; (gx, gy) is that
+ * checkpoint in the frame the node's position is held in -- moved back by the current's drift over the level where the
+ * frame is the ground's).  No child of the node ends nearer to the checkpoint than this.  Rounded down to a float; 0 =
+ * no statement: a NaN state, a node moving astern, a hull without a reach bound, a checkpoint within reach. */
+__device__ inline float node_margin(const DevProblem &P, double gx, double gy, double px, double py, double v0, double rpm0)
+{
+    const double V = v0 + P.reach_dv;
+    const bool bounded = v0 >= 0.0 && V <= P.reach_vcap && fabs(rpm0) <= P.reach_rpm;
+    const double ex = gx - px, ey = gy - py;
+    const double m = sqrt(fma(ex, ex, ey * ey)) * (1.0 - 1.0e-9) - (fma(v0, P.reach_t, P.reach_acc) + 1.0e-6);
+    return bounded && m > 0.0 ? __double2float_rd(m) : 0.0f;
+}
+
+/* the final level's tests: none of these nodes' children can end within dmax (NaN: no bound yet) of the checkpoint */
+__device__ inline bool margin_beyond(float margin, double dmax) { return margin > 0.0f && (double)margin >= dmax; }
+
+/* wave 0 of a workgroup, all 64 lanes: the smallest margin among the parents of one tile (lane i holds parent par0 + i's
+ * offset; parents whose children begin at or after tile_end, and lanes past the level, do not belong to the tile) */
+__device__ inline float tile_margin(const LevelPtrs &A, uint32_t par, uint32_t n_parent, uint32_t off, uint32_t tile_end)
+{
+    float m = (par < n_parent && off < tile_end) ? A.margin[par] : __builtin_inff();
+    for (int d = 32; d >= 1; d >>= 1) m = fminf(m, __shfl_xor(m, d, 64));
+    return m;
+}
 
 /* child c of the level whose parents are A: j-th control pair (throttle outer, rudder inner) of parent `par`.
- * PRUNE / dmax2: as make_child_fast below -- a wave all of whose leaves are too far from the checkpoint to be the level's
+ * PRUNE / dmax: as make_child_fast below -- a wave all of whose leaves are too far from the checkpoint to be the level's
  * winner (or its runner-up within the libm_tie window) skips compareStates and reports +inf. */
 template <bool PRUNE = false>
 __device__ inline Child make_child(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
-                                   uint32_t par, uint32_t j, int level, double dmax2 = 0.0)
+                                   uint32_t par, uint32_t j, int level, double dmax = 0.0)
 {
     double r, t;
     control_pick(P, A.last_r[par], A.last_t[par], j, r, t);
     Child ch;
     ch.s = Veh{A.x[par], A.y[par], A.h[par], A.v[par], A.rpm[par], 0.0, 0.0};
+    const double *cp = cpL + level * CP_STRIDE;
+    if (PRUNE && __builtin_amdgcn_ballot_w64(!margin_beyond(A.margin[par], dmax)) == 0) {   /* every parent of this wave's children */
+        ch.score = ch.cum = __longlong_as_double((long long)KEY_INF);                 /* not simulated at all */
+        ch.r = r; ch.t = t; ch.parent = par;
+        return ch;
+    }
     const Model M = P.model;                                                          /* wave-uniform: scalar registers */
     strict_level(ch.s, r, t, subL, P.nsub, P.cx, P.cy, M);                              /* controller.cpp:149-150 */
     const Weights w{P.wd, P.wh, P.ws};
-    const double *cp = cpL + level * CP_STRIDE;
     bool skip = false;
     if (PRUNE) {
         const double dx = cp[0] - ch.s.x, dy = cp[1] - ch.s.y;
-        const bool far = dx * dx + dy * dy >= dmax2;
+        const bool far = dx * dx + dy * dy >= dmax * dmax;
         skip = __builtin_amdgcn_ballot_w64(!far) == 0;
     }
     ch.score = skip ? __longlong_as_double((long long)KEY_INF) : strict_score(cp, ch.s, w);   /* :155 */
@@ -281,6 +314,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
     __shared__ uint32_t win[2][PARENT_WINDOW];
+    __shared__ double s_dmax[2];
+    __shared__ float s_margin[2];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
@@ -291,30 +326,47 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
         return;
     }
     uint32_t par0 = bpar[tile0];                                     /* the parent of the tile's first child (scan_apply_kernel) */
-    if (threadIdx.x < PARENT_WINDOW) win[0][threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
+    if (threadIdx.x < PARENT_WINDOW) {
+        const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
+        win[0][threadIdx.x] = off;
+        if (!STORE) { const float m = tile_margin(A, p, n_parent, off, (tile0 + 1) * 256); if (threadIdx.x == 0) s_margin[0] = m; }
+    }
+    if (!STORE && threadIdx.x == 0) s_dmax[0] = tree_bound_read(bound);
     stage_problem(P, cpL, subL);                                     /* ends with a barrier */
     uint64_t k = ~0ull, o = ~0ull, second = ~0ull;                   /* this lane's best child and the key of its next best */
     for (uint32_t i = 0; i < tpb && tile0 + i < n_tiles; i++) {
         const uint32_t tile = tile0 + i;
         const bool more = i + 1 < tpb && tile + 1 < n_tiles;
-        uint32_t par_next = 0, off_next = 0;
+        uint32_t par_next = 0, p_next = 0, off_next = 0;
         if (more) {                                                   /* in flight during this tile's arithmetic */
             par_next = bpar[tile + 1];
-            if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[min(par_next + threadIdx.x, n_parent)];
+            p_next = min(par_next + threadIdx.x, n_parent);
+            if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
         }
         const uint32_t c = tile * 256 + threadIdx.x;
-        const double dmax2 = STORE ? 0.0 : tree_bound_read(bound);     /* requested now, used after the substeps */
-        if (c < n_child) {
+        /* the unstored (final) level: the bound as thread 0 read it before the last barrier -- one value for the whole
+         * workgroup, so that leaving a tile out is a uniform decision: no parent of the tile has a child within reach */
+        const double dmax = STORE ? 0.0 : s_dmax[i & 1];
+        const bool skip_tile = !STORE && margin_beyond(s_margin[i & 1], dmax);
+        if (!skip_tile && c < n_child) {
             uint32_t first;
             const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
-            const Child ch = make_child<!STORE>(P, cpL, subL, A, par, c - first, level, dmax2);
-            if (STORE) store_child(B, c, ch);
+            const Child ch = make_child<!STORE>(P, cpL, subL, A, par, c - first, level, dmax);
+            if (STORE) {
+                store_child(B, c, ch);
+                const double *cn = cpL + (level + 1) * CP_STRIDE;     /* (rows past the problem's depth are never read back) */
+                B.margin[c] = level + 1 < P.depth ? node_margin(P, cn[0] - P.reach_cx, cn[1] - P.reach_cy, ch.s.x, ch.s.y, ch.s.v, ch.s.rpm) : 0.0f;
+            }
             const uint64_t kc = key_of(ch.score);
             if (kc < k) { second = k; k = kc; o = c; }                /* (a lane's children come in ascending order: ties keep the first) */
             else if (kc < second) second = kc;
         }
         if (more) {
-            if (threadIdx.x < PARENT_WINDOW) win[(i + 1) & 1][threadIdx.x] = off_next;
+            if (threadIdx.x < PARENT_WINDOW) {
+                win[(i + 1) & 1][threadIdx.x] = off_next;
+                if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile + 2) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
+            }
+            if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
             par0 = par_next;
             __syncthreads();
         }
@@ -323,7 +375,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     block_argmin(k, o, red);
     if (threadIdx.x == 0) {
         pkey[blockIdx.x] = k; pord[blockIdx.x] = o; red[8] = o;
-        /* strict expansion: the window that must stay unpruned is libm_tie's (1e-12); 1e-9 leaves six orders of margin */
+        /* strict expansion: the window that must stay unpruned is libm_tie's (1e-12); 1e-9 leaves six orders of margin.
+         * (Once per workgroup: offering after every tile, as the fast expansion does, made this kernel 27 % slower.) */
         if (!STORE) tree_bound_update(bound, k, P, 1.0e-9);
     }
     __syncthreads();
@@ -366,7 +419,7 @@ __global__ __launch_bounds__(64) void leaf_record_kernel(const DevProblem *__res
  * and scores are the strict path's -- bit for bit what the strict expansion returns for the same leaf. */
 struct FastChild { FastVeh s; double r, t, score, cum; uint32_t parent; };
 
-/* dmax2 (PRUNE): a leaf whose squared distance to its checkpoint is at least dmax2 cannot be the level's winner nor lie
+/* dmax (PRUNE): a leaf whose distance to its checkpoint is at least dmax cannot be the level's winner nor lie
  * inside its refine window, whatever its heading and speed terms are (all three terms of controller.cpp:240 are >= 0, so
  * score >= w_d exp(distance)): when that holds for EVERY leaf of a wave, the wave skips the cost -- atan2, two square roots,
  * exp: ~100 of ~600 instructions per leaf -- and reports +inf.  The bound only ever comes from scores already computed
@@ -374,21 +427,26 @@ struct FastChild { FastVeh s; double r, t, score, cum; uint32_t parent; };
  * first holder and its near-tie set are the same with any bound, including none. */
 template <bool PRUNE = false>
 __device__ inline FastChild make_child_fast(const DevProblem &P, const double *cpL, const double *subL, const LevelPtrs &A,
-                                            uint32_t par, uint32_t j, int level, double dmax2 = 0.0)
+                                            uint32_t par, uint32_t j, int level, double dmax = 0.0)
 {
     FastChild ch;
     control_pick(P, A.last_r[par], A.last_t[par], j, ch.r, ch.t);
     ch.s.x = A.x[par]; ch.s.y = A.y[par]; ch.s.sh = A.h[par]; ch.s.ch = A.cmg[par]; ch.s.v = A.v[par]; ch.s.rpm = A.rpm[par];
     ch.s.delta = 0;
+    ch.parent = par;
+    const double *cp = cpL + level * CP_STRIDE;
+    if (PRUNE && __builtin_amdgcn_ballot_w64(!margin_beyond(A.margin[par], dmax)) == 0) {   /* every parent of this wave's children */
+        ch.score = ch.cum = __longlong_as_double((long long)KEY_INF);              /* not simulated at all */
+        return ch;
+    }
     const Model M = P.model;
     if (P.head_uniform) fast_level_head_uniform<true>(ch.s, ch.r, ch.t, subL, P.nsub, M, P.head_uniform == 2);      /* the reference's own 1-s level */
     else fast_level<SUB_STRIDE, true>(ch.s, ch.r, ch.t, subL, P.nsub, M);
     const Weights w{P.wd, P.wh, P.ws};
-    const double *cp = cpL + level * CP_STRIDE;
     bool skip = false;
     if (PRUNE) {
         const double ex = cp[6] - ch.s.x, ey = cp[7] - ch.s.y;
-        const bool far = fma(ex, ex, ey * ey) >= dmax2;                /* false for a NaN state and for "no bound yet" (NaN) */
+        const bool far = fma(ex, ex, ey * ey) >= dmax * dmax;          /* false for a NaN state and for "no bound yet" (NaN) */
         skip = __builtin_amdgcn_ballot_w64(!far) == 0;                 /* wave-uniform: every active lane is far */
     }
     ch.score = skip ? __longlong_as_double((long long)KEY_INF) : fast_score<true>(cp, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
@@ -398,7 +456,7 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
 }
 
 /* The pruning bound of an unstored (final) level: bound[0] = the smallest score key any finished workgroup has reported,
- * bound[1] = bits of dmax2 = (log(limit / w_d))^2 with limit = twice the refine window above that score (strict
+ * bound[1] = bits of dmax = log(limit / w_d) with limit = twice the refine window above that score (strict
  * expansion: the libm_tie window, which is far narrower) -- both only ever decrease (atomicMin on the bit patterns of
  * non-negative doubles).  Thread 0 of a workgroup, once, after its argmin. */
 __device__ inline void tree_bound_update(uint64_t *bound, uint64_t k, const DevProblem &P, double rel)
@@ -409,7 +467,24 @@ __device__ inline void tree_bound_update(uint64_t *bound, uint64_t k, const DevP
     const double limit = mpc_refine_limit(__longlong_as_double((long long)k), rel, P.wd, P.wh, P.ws);
     const double dmax = log(limit / P.wd);                             /* w_d == 0: +inf, nothing is ever far */
     if (!(dmax >= 0.0)) return;                                        /* (a score below w_d cannot happen: exp >= 1) */
-    atomicMin((unsigned long long *)(bound + 1), (unsigned long long)__double_as_longlong(dmax * dmax));
+    atomicMin((unsigned long long *)(bound + 1), (unsigned long long)__double_as_longlong(dmax));
+}
+
+/* After a tile of the unstored level: a wave one of whose scores beats the best key it saw before the tile (seen) reports
+ * its minimum -- rare once the first tiles of a level are through, so the level's bound is there after the first tile
+ * of the first workgroups instead of after their last.  Every lane of the wave must call (kc = all ones for a lane
+ * without a child). */
+__device__ inline void tree_bound_offer(uint64_t *bound, uint64_t seen, uint64_t kc, const DevProblem &P, double rel)
+{
+    if (__builtin_amdgcn_ballot_w64(kc < seen) == 0) return;          /* wave-uniform */
+    uint64_t m = kc;
+    for (int d = 32; d >= 1; d >>= 1) m = min(m, (uint64_t)__shfl_xor((unsigned long long)m, d, 64));
+    if ((threadIdx.x & 63) == 0) tree_bound_update(bound, m, P, rel);
+}
+
+__device__ inline uint64_t tree_bound_key(const uint64_t *bound)
+{
+    return __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* the current bound, read past the caches (another workgroup's atomic wrote it) */
@@ -429,6 +504,8 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
     __shared__ uint32_t win[2][PARENT_WINDOW];
+    __shared__ double s_dmax[2];
+    __shared__ float s_margin[2];
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
@@ -439,7 +516,12 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
         return;
     }
     uint32_t par0 = bpar[tile0];
-    if (threadIdx.x < PARENT_WINDOW) win[0][threadIdx.x] = A.offset[min(par0 + threadIdx.x, n_parent)];
+    if (threadIdx.x < PARENT_WINDOW) {
+        const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
+        win[0][threadIdx.x] = off;
+        if (!STORE) { const float m = tile_margin(A, p, n_parent, off, (tile0 + 1) * 256); if (threadIdx.x == 0) s_margin[0] = m; }
+    }
+    if (!STORE && threadIdx.x == 0) s_dmax[0] = tree_bound_read(bound);
     stage_problem(P, cpL, subL);
     uint64_t k = ~0ull, o = ~0ull;
     double keys[EXPAND_TILES];                                         /* this lane's scores, for the near-tie count */
@@ -449,29 +531,43 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
         const uint32_t tile = tile0 + i;
         if (i < tpb && tile < n_tiles) {                               /* uniform */
             const bool more = i + 1 < tpb && tile + 1 < n_tiles;
-            uint32_t par_next = 0, off_next = 0;
+            uint32_t par_next = 0, p_next = 0, off_next = 0;
             if (more) {
                 par_next = bpar[tile + 1];
-                if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[min(par_next + threadIdx.x, n_parent)];
+                p_next = min(par_next + threadIdx.x, n_parent);
+                if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
             }
             const uint32_t c = tile * 256 + threadIdx.x;
-            /* the unstored (final) level: this tile's pruning bound, requested now, used after the substeps */
-            const double dmax2 = STORE ? 0.0 : tree_bound_read(bound);
-            if (c < n_child) {
-                uint32_t first;
-                const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
-                const FastChild ch = make_child_fast<!STORE>(P, cpL, subL, A, par, c - first, level, dmax2);
-                if (STORE) {
-                    B.x[c] = ch.s.x; B.y[c] = ch.s.y; B.h[c] = ch.s.sh; B.cmg[c] = ch.s.ch; B.v[c] = ch.s.v; B.rpm[c] = ch.s.rpm;
-                    B.sog[c] = ch.s.delta; B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.cum[c] = ch.cum; B.last_score[c] = ch.score;
-                    B.parent[c] = ch.parent;
+            /* the unstored (final) level: the bound as thread 0 read it before the last barrier -- one value for the whole
+             * workgroup, so that leaving a tile out is a uniform decision: no parent of the tile has a child within reach */
+            const double dmax = STORE ? 0.0 : s_dmax[i & 1];
+            const bool skip_tile = !STORE && margin_beyond(s_margin[i & 1], dmax);
+            if (!skip_tile) {
+                const uint64_t seen = STORE ? 0 : tree_bound_key(bound);
+                uint64_t kc = ~0ull;
+                if (c < n_child) {
+                    uint32_t first;
+                    const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
+                    const FastChild ch = make_child_fast<!STORE>(P, cpL, subL, A, par, c - first, level, dmax);
+                    if (STORE) {
+                        B.x[c] = ch.s.x; B.y[c] = ch.s.y; B.h[c] = ch.s.sh; B.cmg[c] = ch.s.ch; B.v[c] = ch.s.v; B.rpm[c] = ch.s.rpm;
+                        B.sog[c] = ch.s.delta; B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.cum[c] = ch.cum; B.last_score[c] = ch.score;
+                        B.parent[c] = ch.parent;
+                        const double *cn = cpL + (level + 1) * CP_STRIDE;   /* (rows past the problem's depth are never read back) */
+                        B.margin[c] = level + 1 < P.depth ? node_margin(P, cn[6], cn[7], ch.s.x, ch.s.y, ch.s.v, ch.s.rpm) : 0.0f;
+                    }
+                    kc = key_of(ch.score);
+                    keys[i] = __longlong_as_double((long long)kc);
+                    lex_min(k, o, kc, (uint64_t)c);
                 }
-                const uint64_t kc = key_of(ch.score);
-                keys[i] = __longlong_as_double((long long)kc);
-                lex_min(k, o, kc, (uint64_t)c);
+                if (!STORE) tree_bound_offer(bound, seen, kc, P, 2.0 * refine_rel);
             }
             if (more) {
-                if (threadIdx.x < PARENT_WINDOW) win[(i + 1) & 1][threadIdx.x] = off_next;
+                if (threadIdx.x < PARENT_WINDOW) {
+                    win[(i + 1) & 1][threadIdx.x] = off_next;
+                    if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile + 2) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
+                }
+                if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
                 par0 = par_next;
                 __syncthreads();
             }
@@ -492,7 +588,6 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     __syncthreads();
     if (threadIdx.x == 0) {
         pkey[blockIdx.x] = k; pord[blockIdx.x] = o; pcnt[blockIdx.x] = *cnt;
-        if (!STORE) tree_bound_update(bound, red[8], P, 2.0 * refine_rel);
     }
 }
 
@@ -569,7 +664,7 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     const double limit = mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws);
     uint32_t overflow = 0;
     for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) {
-        if (__longlong_as_double((long long)pkey[j]) > limit) continue;
+        if (!(__longlong_as_double((long long)pkey[j]) <= limit)) continue;     /* (all ones -- a workgroup none of whose tiles was expanded -- reads as NaN) */
         if (pcnt[j] <= 1) {
             const uint32_t at = atomicAdd(&s_n, 1u);
             if (at < LIST_CAP) s_list[at] = pord[j];
@@ -793,6 +888,7 @@ static void free_level(TreeLevelBuf &b)
     (void)hipFree(b.x); (void)hipFree(b.y); (void)hipFree(b.h); (void)hipFree(b.v); (void)hipFree(b.rpm);
     (void)hipFree(b.cmg); (void)hipFree(b.sog); (void)hipFree(b.last_r); (void)hipFree(b.last_t); (void)hipFree(b.cum);
     (void)hipFree(b.last_score); (void)hipFree(b.parent); (void)hipFree(b.count); (void)hipFree(b.offset);
+    (void)hipFree(b.margin);
     b = TreeLevelBuf();
 }
 
@@ -820,6 +916,7 @@ static int ensure_level(mpc_hip_handle *h, TreeLevelBuf &b, size_t n)
     HIP_TRY(hipMalloc(&b.parent, sizeof(uint32_t) * cap));
     HIP_TRY(hipMalloc(&b.count, sizeof(uint32_t) * cap));
     HIP_TRY(hipMalloc(&b.offset, sizeof(uint32_t) * (cap + 1)));
+    HIP_TRY(hipMalloc(&b.margin, sizeof(float) * cap));
     b.cap = cap;
     return MPC_OK;
 }

@@ -2,7 +2,7 @@
 runs -- 8,400 trees, 3,000 + 3,000 problems, 1,000 shard splits -- are builder-run: profiles/r0?_fuzz_*.txt):
 
   * 200 random tree searches of depth 2-4 against the oracle's DFS, both expansions; a chosen leaf may differ from the
-    oracle's only where the level carries libm_tie (mpc_hip.h)
+    oracle's only where the level carries libm_tie (mpc_hip.h); 150 more with a random boat per problem
   * 200 random problems with arbitrary explicit FP32 controls (a tenth out of range), ragged set sizes, both precisions,
     both selections: no wrong choice, errors within the contract (relative to max(|cost|, 1 % of the weights' sum))
   * 100 random problems cut into 2-8 shards of random sizes: the exact cross-shard decision is the whole set's winner
@@ -31,6 +31,19 @@ def test_tree_slice(solver):
     assert out["bad"] == [], out["bad"][:5]
     assert out["worst"] <= 1e-12
     print("tree slice: 200 problems, flagged libm ties:", len(out["libm_ties"]), "worst level-score error %.3g" % out["worst"])
+
+
+def test_tree_slice_with_random_hulls(solver):
+    """the same with a boat of its own per problem (150 kg - 6 t, 0.5 - 20 kW ...): the final level leaves out nodes whose
+    children cannot come near enough to win, by a bound on how far THIS hull can travel in one level (mpc_tree.hip:
+    node_margin) -- a bound on the wrong side would lose the oracle's winner here"""
+    import fuzz_tree
+    out = fuzz_tree.run(150, seed=20266, solver=solver, verbose=False, hulls=True)
+    assert out["bad"] == [], out["bad"][:5]
+    # (plain relative error of a level's best score: where one weight alone is non-zero the score is a lone difference that
+    # cancels to 1e-4 of its operands -- the long runs of profiles/r03_fuzz_tree.txt show up to 1e-9 there, never a wrong leaf)
+    assert out["worst"] <= 1e-9
+    print("tree slice, random hulls: 150 problems, flagged libm ties:", len(out["libm_ties"]), "worst level-score error %.3g" % out["worst"])
 
 
 def test_explicit_slice(solver):
