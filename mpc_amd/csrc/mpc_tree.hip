@@ -271,6 +271,18 @@ __device__ inline uint32_t find_parent(const uint32_t *offset, uint32_t n_parent
     return lo;
 }
 
+/* the same when the parent of the first child of c's tile is known (bpar[c / 256], scan_apply_kernel): c's parent is one
+ * of the next PARENT_WINDOW nodes -- six dependent loads instead of ~25 */
+__device__ inline uint32_t find_parent_from(const uint32_t *offset, uint32_t par0, uint32_t n_parent, uint32_t c)
+{
+    uint32_t lo = par0, hi = min(par0 + 64u, n_parent);   /* offset[lo] <= c < offset[hi] (offset[n_parent] = the level's size) */
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (offset[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 /* A node has at least 3 x 2 children (controller.cpp:121-146), so the 256 children of a workgroup belong to at most
  * 44 consecutive parents: the first one comes from bpar[] (written by the scan), the workgroup stages a window of
  * offsets in LDS, and every lane finds its parent there -- no search in global memory (a binary search over a
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
             const Child ch = make_child<!STORE>(P, cpL, subL, A, par, c - first, level, dmax);
             if (STORE) {
                 store_child(B, c, ch);
+                B.count[c] = control_count(P, ch.r, ch.t);            /* its children-to-be, for the next level's scan */
                 const double *cn = cpL + (level + 1) * CP_STRIDE;     /* (rows past the problem's depth are never read back) */
                 B.margin[c] = level + 1 < P.depth ? node_margin(P, cn[0] - P.reach_cx, cn[1] - P.reach_cy, ch.s.x, ch.s.y, ch.s.v, ch.s.rpm) : 0.0f;
             }
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(64) void leaf_record_kernel(const DevProblem *__res
  * every leaf whose fast last-step score is within MPC_REFINE_REL of the level's minimum is re-evaluated along its
  * whole path from the root with the strict model, the strict (score, ordinal) decides, and the returned trajectory
  * and scores are the strict path's -- bit for bit what the strict expansion returns for the same leaf. */
-struct FastChild { FastVeh s; double r, t, score, cum; uint32_t parent; };
+struct FastChild { FastVeh s; double r, t, score; uint32_t parent; };
 
 /* dmax (PRUNE): a leaf whose distance to its checkpoint is at least dmax cannot be the level's winner nor lie
  * inside its refine window, whatever its heading and speed terms are (all three terms of controller.cpp:240 are >= 0, so
@@ -436,7 +449,7 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
     ch.parent = par;
     const double *cp = cpL + level * CP_STRIDE;
     if (PRUNE && __builtin_amdgcn_ballot_w64(!margin_beyond(A.margin[par], dmax)) == 0) {   /* every parent of this wave's children */
-        ch.score = ch.cum = __longlong_as_double((long long)KEY_INF);              /* not simulated at all */
+        ch.score = __longlong_as_double((long long)KEY_INF);                       /* not simulated at all */
         return ch;
     }
     const Model M = P.model;
@@ -450,8 +463,6 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
         skip = __builtin_amdgcn_ballot_w64(!far) == 0;                 /* wave-uniform: every active lane is far */
     }
     ch.score = skip ? __longlong_as_double((long long)KEY_INF) : fast_score<true>(cp, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
-    ch.cum = A.cum[par] + ch.score;
-    ch.parent = par;
     return ch;
 }
 
@@ -551,8 +562,10 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                     const FastChild ch = make_child_fast<!STORE>(P, cpL, subL, A, par, c - first, level, dmax);
                     if (STORE) {
                         B.x[c] = ch.s.x; B.y[c] = ch.s.y; B.h[c] = ch.s.sh; B.cmg[c] = ch.s.ch; B.v[c] = ch.s.v; B.rpm[c] = ch.s.rpm;
-                        B.sog[c] = ch.s.delta; B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.cum[c] = ch.cum; B.last_score[c] = ch.score;
-                        B.parent[c] = ch.parent;
+                        /* (sog, cum, last_score stay unwritten: fast nodes are only ever parents -- what is returned comes
+                         * from the strict model along the winner's path -- and a level is bound by these stores) */
+                        B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.parent[c] = ch.parent;
+                        B.count[c] = control_count(P, ch.r, ch.t);        /* its children-to-be, for the next level's scan */
                         const double *cn = cpL + (level + 1) * CP_STRIDE;   /* (rows past the problem's depth are never read back) */
                         B.margin[c] = level + 1 < P.depth ? node_margin(P, cn[6], cn[7], ch.s.x, ch.s.y, ch.s.v, ch.s.rpm) : 0.0f;
                     }
@@ -595,10 +608,10 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
 struct PathCtl { double r[MPC_MAX_DEPTH], t[MPC_MAX_DEPTH]; };
 
 __device__ inline void path_controls(const DevProblem &P, const LevelPtrs *levels, int L, uint32_t n_parent, uint32_t c,
-                                     PathCtl &pc)
+                                     PathCtl &pc, const uint32_t *bpar = nullptr)
 {
     const LevelPtrs A = levels[L];
-    uint32_t node = find_parent(A.offset, n_parent, c);
+    uint32_t node = bpar ? find_parent_from(A.offset, bpar[c >> 8], n_parent, c) : find_parent(A.offset, n_parent, c);
     control_pick(P, A.last_r[node], A.last_t[node], c - A.offset[node], pc.r[L], pc.t[L]);
     for (int l = L; l >= 1; l--) {
         const LevelPtrs N = levels[l];
@@ -630,7 +643,7 @@ __device__ inline void strict_path(const DevProblem &P, const double *cpL, const
 struct TreeFinishLds {
     double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     uint64_t s_list[LIST_CAP];
-    uint64_t red[8];
+    uint64_t red[32];                  /* block_argmin: two words per wave, up to 16 waves */
     uint64_t s_win[2];
     uint32_t s_blocks[256];
     uint32_t s_n, s_nb;
@@ -639,7 +652,7 @@ struct TreeFinishLds {
 __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
                                         int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
                                         const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
-                                        const uint32_t *__restrict__ pcnt, uint32_t nblk,
+                                        const uint32_t *__restrict__ pcnt, uint32_t nblk, const uint32_t *__restrict__ bpar,
                                         uint64_t *__restrict__ out, TreeFinishLds &S)
 {
     double *lds = S.lds;
@@ -650,8 +663,19 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (threadIdx.x == 0) { s_n = 0; s_nb = 0; }
     stage_problem(P, cpL, subL);
+    /* (one workgroup walks all the expansion's workgroups: eight independent loads in flight per lane and trip -- a plain
+     * loop is one memory latency per trip, 0.3 ms of them on a 1.5e5-workgroup level) */
     uint64_t k = ~0ull, o = ~0ull;
-    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
+    for (uint32_t j0 = threadIdx.x; j0 < nblk; j0 += 8 * blockDim.x) {
+        uint64_t kk[8], oo[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = j0 + u * blockDim.x;
+            kk[u] = j < nblk ? pkey[j] : ~0ull; oo[u] = j < nblk ? pord[j] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) lex_min(k, o, kk[u], oo[u]);
+    }
     block_argmin(k, o, red);
     if (threadIdx.x == 0) { s_win[0] = k; s_win[1] = o; }
     __syncthreads();
@@ -663,24 +687,32 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     const double m = __longlong_as_double((long long)k);
     const double limit = mpc_refine_limit(m, refine_rel, P.wd, P.wh, P.ws);
     uint32_t overflow = 0;
-    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) {
-        if (!(__longlong_as_double((long long)pkey[j]) <= limit)) continue;     /* (all ones -- a workgroup none of whose tiles was expanded -- reads as NaN) */
-        if (pcnt[j] <= 1) {
-            const uint32_t at = atomicAdd(&s_n, 1u);
-            if (at < LIST_CAP) s_list[at] = pord[j];
-        } else {                                             /* several near-ties in one expansion workgroup */
-            const uint32_t at = atomicAdd(&s_nb, 1u);
-            if (at < 256) s_blocks[at] = j;
+    for (uint32_t j0 = threadIdx.x; j0 < nblk; j0 += 8 * blockDim.x) {
+        uint64_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t j = j0 + u * blockDim.x; kk[u] = j < nblk ? pkey[j] : ~0ull; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = j0 + u * blockDim.x;
+            if (!(__longlong_as_double((long long)kk[u]) <= limit)) continue;     /* (all ones -- a workgroup none of whose tiles was expanded, or no workgroup -- reads as NaN) */
+            if (pcnt[j] <= 1) {
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at < LIST_CAP) s_list[at] = pord[j];
+            } else {                                             /* several near-ties in one expansion workgroup */
+                const uint32_t at = atomicAdd(&s_nb, 1u);
+                if (at < 256) s_blocks[at] = j;
+            }
         }
     }
     __syncthreads();
     if (s_nb > 256) overflow = 1;
-    /* those workgroups' children once more, a lane per child, to see which of them are near */
+    /* those workgroups' children once more, a lane per child and 256 lanes per tile, to see which of them are near */
     const LevelPtrs A = levels[L];
-    for (uint32_t b = 0; b < min(s_nb, 256u) * tpb; b++) {
-        const uint32_t c = (s_blocks[b / tpb] * tpb + b % tpb) * 256 + threadIdx.x;
+    for (uint32_t b = threadIdx.x >> 8; b < min(s_nb, 256u) * tpb; b += blockDim.x >> 8) {
+        const uint32_t tile = s_blocks[b / tpb] * tpb + b % tpb;
+        const uint32_t c = tile * 256 + (threadIdx.x & 255);
         if (c < n_child) {
-            const uint32_t par = find_parent(A.offset, n_parent, c);
+            const uint32_t par = find_parent_from(A.offset, bpar[tile], n_parent, c);
             const FastChild ch = make_child_fast(P, cpL, subL, A, par, c - A.offset[par], L);
             if (ch.score <= limit) {
                 const uint32_t at = atomicAdd(&s_n, 1u);
@@ -696,7 +728,7 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     double my_last = 0, my_cum = 0;
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         PathCtl pc;
-        path_controls(P, levels, L, n_parent, (uint32_t)s_list[e], pc);
+        path_controls(P, levels, L, n_parent, (uint32_t)s_list[e], pc, bpar);
         double last, cum;
         strict_path(P, cpL, subL, pc, L, last, cum, nullptr);
         const uint64_t ke = key_of(last);
@@ -720,14 +752,15 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     }
 }
 
-__global__ __launch_bounds__(256) void tree_finish_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
+#define TREE_FINISH_THREADS 512
+__global__ __launch_bounds__(TREE_FINISH_THREADS) void tree_finish_kernel(const DevProblem *__restrict__ probs, const LevelPtrs *__restrict__ levels,
                                                           int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
                                                           const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
                                                           const uint32_t *__restrict__ pcnt, uint32_t nblk,
-                                                          uint64_t *__restrict__ out)
+                                                          const uint32_t *__restrict__ bpar, uint64_t *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) TreeFinishLds S;
-    tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, out, S);
+    tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, bpar, out, S);
 }
 
 /* ---- the blind shallow levels --------------------------------------------------------------------------------
@@ -754,7 +787,7 @@ __global__ __launch_bounds__(256) void tree_post_kernel(const DevProblem *__rest
     const uint32_t n_tiles = (n_child + 255) / 256, nblk = (n_tiles + tpb - 1) / tpb;
     const LevelPtrs A = levels[L], B = levels[L + 1];
     if (FAST) {
-        tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, out, S);
+        tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, bpar, out, S);
     } else {
         stage_problem(P, S.lds, S.lds + MPC_MAX_DEPTH * CP_STRIDE);
         uint64_t k = ~0ull, o = ~0ull;
@@ -1092,7 +1125,8 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             HIP_TRY(hipMalloc(&h->d_scan_tmp, sizeof(uint32_t) * ((size_t)ntile + 2) * 2));
             h->cap_scan_tmp = ((size_t)ntile + 2) * 2;
         }
-        hipLaunchKernelGGL(count_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n);
+        /* (every expansion leaves its children's own child counts behind; only the root has none yet) */
+        if (it == 0) hipLaunchKernelGGL(count_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n);
         const LevelPtrs PA = ptrs(A);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(SCAN_BLOCK), 0, h->stream, PA.count, n, h->d_scan_tmp);
         hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->d_scan_tmp, ntile);
@@ -1136,8 +1170,8 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             else
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
                                    nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound);
-            hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
-                               (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_winners);
+            hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(TREE_FINISH_THREADS), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
+                               (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_bpar, h->d_winners);
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
