@@ -30,9 +30,10 @@ struct DevProblem {
     int32_t pad0; double pad1;   /* keeps cp 16-byte aligned for the staging vectors */
     /* How far a node can travel through the water in one level (mpc_pack_problem derives it from the hull and the schedule;
      * the tree search's final level leaves out parents none of whose children can come near enough to win, mpc_tree.hip):
-     * a node with 0 <= v, v + reach_dv <= reach_vcap and |rpm| <= reach_rpm moves at most v * reach_t + reach_acc.
-     * reach_vcap < 0: no such bound for this hull / schedule. */
-    double reach_dv, reach_t, reach_vcap, reach_rpm, reach_cx, reach_cy, reach_acc, reach_pad;
+     * a node with 0 <= v, v + reach_dv <= reach_vcap and |rpm| <= reach_rpm moves at most v * reach_t + reach_acc, and its
+     * heading turns by at most reach_yaw * max(reach_sqrtps, v + reach_dv).  reach_vcap < 0: no such bound for this
+     * hull / schedule. */
+    double reach_dv, reach_t, reach_vcap, reach_rpm, reach_cx, reach_cy, reach_acc, reach_yaw, reach_sqrtps, reach_pad;
     mpc::Model model;            /* this problem's hull (mpc_hip_set_model; VehicleState.h:86-101) */
     double cp[MPC_MAX_DEPTH * CP_STRIDE];
     double sub[MPC_MAX_SUBSTEPS * SUB_STRIDE];
@@ -201,6 +202,7 @@ struct mpc_hip_handle {
     std::vector<TreeLevelBuf> tree;
     uint32_t *d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;
     uint32_t *d_bpar = nullptr; size_t cap_bpar = 0;              /* first parent of every 256-child workgroup */
+    uint32_t *d_tile_list = nullptr; size_t cap_tile_list = 0;   /* tree search, final level: [0] count, [1..2] seed tiles, [4..] the short list */
     LevelPtrs *d_level_ptrs = nullptr;                           /* [MPC_MAX_DEPTH + 2], fast-mode path walks */
     std::vector<LevelPtrs> h_level_ptrs;                         /* its host image (copies are asynchronous) */
     uint64_t *h_pair = nullptr;                                  /* pinned, 4 uint64 */

@@ -195,18 +195,46 @@ __device__ inline double tree_bound_read(const uint64_t *bound);
 __device__ inline uint64_t tree_bound_key(const uint64_t *bound);
 __device__ inline void tree_bound_offer(uint64_t *bound, uint64_t seen, uint64_t kc, const DevProblem &P, double rel);
 
-/* What a stored node keeps for the expansion of its children, should that be the search's final level: by how much the
- * NEXT level's checkpoint lies beyond what the node can travel in one level (DevProblem.reach_*; (gx, gy) is that
- * checkpoint in the frame the node's position is held in -- moved back by the current's drift over the level where the
- * frame is the ground's).  No child of the node ends nearer to the checkpoint than this.  Rounded down to a float; 0 =
- * no statement: a NaN state, a node moving astern, a hull without a reach bound, a checkpoint within reach. */
-__device__ inline float node_margin(const DevProblem &P, double gx, double gy, double px, double py, double v0, double rpm0)
+/* What a stored node keeps for the expansion of its children, should that be the search's final level: a lower bound on
+ * the distance between the NEXT level's checkpoint and wherever a child of the node can end.  (gx, gy) is that checkpoint
+ * in the frame the node's position is held in -- moved back by the current's drift over the level where the frame is the
+ * ground's; (ux, uy) = (sin, cos) of the node's heading, any length.
+ *   Through the water a child ends at p + sum v' dt (sin h, cos h) with 0 <= v', sum v' dt <= s = v0 T + a T (T + dt) / 2 and
+ *   |h - h0| <= D = the most the rudder can turn the vessel in a level (DevProblem.reach_*, mpc_pack_problem): a positive
+ *   combination of unit vectors within D of the heading, so the end point lies in the circular sector of radius s and
+ *   half-angle D about the heading (D < pi/2; a disc otherwise).  The margin is the checkpoint's distance to that sector.
+ * Rounded down to a float; 0 = no statement: a NaN state, a node moving astern, a hull without a reach bound, a
+ * checkpoint within reach. */
+__device__ inline float node_margin(const DevProblem &P, double gx, double gy, double px, double py, double v0, double rpm0,
+                                    double ux, double uy)
 {
     const double V = v0 + P.reach_dv;
     const bool bounded = v0 >= 0.0 && V <= P.reach_vcap && fabs(rpm0) <= P.reach_rpm;
     const double ex = gx - px, ey = gy - py;
-    const double m = sqrt(fma(ex, ex, ey * ey)) * (1.0 - 1.0e-9) - (fma(v0, P.reach_t, P.reach_acc) + 1.0e-6);
+    const double d = sqrt(fma(ex, ex, ey * ey));
+    const double s = fma(v0, P.reach_t, P.reach_acc) + 1.0e-6;
+    double m = d - s;                                                    /* the disc */
+    const double D = fma(P.reach_yaw, fmax(P.reach_sqrtps, V), 1.0e-6);
+    const double un = sqrt(fma(ux, ux, uy * uy)) * d;
+    if (D < 1.5 && un > 0.0) {
+        const double cf = fma(ex, ux, ey * uy) / un, sf = fabs(fma(ex, uy, -(ey * ux))) / un;   /* angle checkpoint / heading */
+        double sD, cD;
+        sincos(D, &sD, &cD);
+        if (cf < cD) {                                                   /* outside the sector's angle: its edge decides */
+            const double cq = fma(cf, cD, sf * sD), sq = fma(sf, cD, -(cf * sD));              /* angle to the nearer edge */
+            const double along = d * cq, perp = d * fmax(sq, 0.0);
+            m = cq <= 0.0 ? d : (along <= s ? perp : sqrt(fma(along - s, along - s, perp * perp)));
+        }
+    }
+    m = m * (1.0 - 1.0e-9) - 1.0e-6;
     return bounded && m > 0.0 ? __double2float_rd(m) : 0.0f;
+}
+
+__device__ inline float strict_node_margin(const DevProblem &P, const double *cp_next, const Veh &s)
+{
+    double sh, ch;
+    sincos(s.h, &sh, &ch);
+    return node_margin(P, cp_next[0] - P.reach_cx, cp_next[1] - P.reach_cy, s.x, s.y, s.v, s.rpm, sh, ch);
 }
 
 /* the final level's tests: none of these nodes' children can end within dmax (NaN: no bound yet) of the checkpoint */
@@ -321,7 +349,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
                                                      const uint32_t *__restrict__ bpar, LevelPtrs B, uint32_t n_child, int level,
                                                      uint32_t tpb, uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
                                                      uint64_t *__restrict__ pkey2, const uint64_t *__restrict__ meta_parent,
-                                                     uint64_t *bound)
+                                                     uint64_t *bound, const uint32_t *__restrict__ tile_list, uint32_t n_list)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
@@ -331,12 +359,14 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
-    const uint32_t n_tiles = (n_child + 255) / 256;
-    const uint32_t tile0 = blockIdx.x * tpb;
-    if (tile0 >= n_tiles) {                                          /* uniform: a workgroup beyond the level */
+    /* tile_list (the final level's short list, tile_select_kernel): the workgroup's tiles are entries of the list */
+    const uint32_t n_tiles = tile_list ? n_list : (n_child + 255) / 256;
+    const uint32_t slot0 = blockIdx.x * tpb;
+    if (slot0 >= n_tiles) {                                          /* uniform: a workgroup beyond the level */
         if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; pkey2[blockIdx.x] = ~0ull; }
         return;
     }
+    const uint32_t tile0 = tile_list ? tile_list[slot0] : slot0;
     uint32_t par0 = bpar[tile0];                                     /* the parent of the tile's first child (scan_apply_kernel) */
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
@@ -346,12 +376,13 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     if (!STORE && threadIdx.x == 0) s_dmax[0] = tree_bound_read(bound);
     stage_problem(P, cpL, subL);                                     /* ends with a barrier */
     uint64_t k = ~0ull, o = ~0ull, second = ~0ull;                   /* this lane's best child and the key of its next best */
-    for (uint32_t i = 0; i < tpb && tile0 + i < n_tiles; i++) {
-        const uint32_t tile = tile0 + i;
-        const bool more = i + 1 < tpb && tile + 1 < n_tiles;
-        uint32_t par_next = 0, p_next = 0, off_next = 0;
+    uint32_t tile = tile0;
+    for (uint32_t i = 0; i < tpb && slot0 + i < n_tiles; i++) {
+        const bool more = i + 1 < tpb && slot0 + i + 1 < n_tiles;
+        uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0;
         if (more) {                                                   /* in flight during this tile's arithmetic */
-            par_next = bpar[tile + 1];
+            tile_next = tile_list ? tile_list[slot0 + i + 1] : tile + 1;
+            par_next = bpar[tile_next];
             p_next = min(par_next + threadIdx.x, n_parent);
             if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
         }
@@ -368,7 +399,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
                 store_child(B, c, ch);
                 B.count[c] = control_count(P, ch.r, ch.t);            /* its children-to-be, for the next level's scan */
                 const double *cn = cpL + (level + 1) * CP_STRIDE;     /* (rows past the problem's depth are never read back) */
-                B.margin[c] = level + 1 < P.depth ? node_margin(P, cn[0] - P.reach_cx, cn[1] - P.reach_cy, ch.s.x, ch.s.y, ch.s.v, ch.s.rpm) : 0.0f;
+                B.margin[c] = level + 1 < P.depth ? strict_node_margin(P, cn, ch.s) : 0.0f;
             }
             const uint64_t kc = key_of(ch.score);
             if (kc < k) { second = k; k = kc; o = c; }                /* (a lane's children come in ascending order: ties keep the first) */
@@ -377,10 +408,10 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
         if (more) {
             if (threadIdx.x < PARENT_WINDOW) {
                 win[(i + 1) & 1][threadIdx.x] = off_next;
-                if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile + 2) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
+                if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
             }
             if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
-            par0 = par_next;
+            par0 = par_next; tile = tile_next;
             __syncthreads();
         }
     }
@@ -405,7 +436,19 @@ __device__ inline uint64_t level_runner_up(const uint64_t *__restrict__ pkey, co
                                            const uint64_t *__restrict__ pkey2, uint32_t nblk, uint64_t winner, uint64_t *red)
 {
     uint64_t ru = ~0ull, zero = 0;
-    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) ru = min(ru, pord[j] == winner ? pkey2[j] : pkey[j]);
+    for (uint32_t j0 = threadIdx.x; j0 < nblk; j0 += 8 * blockDim.x) {      /* eight loads in flight per lane, as in tree_finish_body */
+        uint64_t kk[8], oo[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = j0 + u * blockDim.x;
+            kk[u] = j < nblk ? pkey[j] : ~0ull; oo[u] = j < nblk ? pord[j] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = j0 + u * blockDim.x;
+            if (j < nblk) ru = min(ru, oo[u] == winner ? pkey2[j] : kk[u]);
+        }
+    }
     block_argmin(ru, zero, red);
     return ru;
 }
@@ -510,7 +553,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                                                           double refine_rel, uint32_t tpb,
                                                           uint64_t *__restrict__ pkey, uint64_t *__restrict__ pord,
                                                           uint32_t *__restrict__ pcnt, const uint64_t *__restrict__ meta_parent,
-                                                          uint64_t *bound)
+                                                          uint64_t *bound, const uint32_t *__restrict__ tile_list, uint32_t n_list)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ uint64_t red[10];
@@ -520,12 +563,14 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
-    const uint32_t n_tiles = (n_child + 255) / 256;
-    const uint32_t tile0 = blockIdx.x * tpb;
-    if (tile0 >= n_tiles) {
+    /* tile_list (the final level's short list, tile_select_kernel): the workgroup's tiles are entries of the list */
+    const uint32_t n_tiles = tile_list ? n_list : (n_child + 255) / 256;
+    const uint32_t slot0 = blockIdx.x * tpb;
+    if (slot0 >= n_tiles) {
         if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; pcnt[blockIdx.x] = 0; }
         return;
     }
+    const uint32_t tile0 = tile_list ? tile_list[slot0] : slot0;
     uint32_t par0 = bpar[tile0];
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
@@ -536,15 +581,16 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     stage_problem(P, cpL, subL);
     uint64_t k = ~0ull, o = ~0ull;
     double keys[EXPAND_TILES];                                         /* this lane's scores, for the near-tie count */
+    uint32_t tile = tile0;
 #pragma unroll
     for (uint32_t i = 0; i < EXPAND_TILES; i++) {
         keys[i] = __longlong_as_double((long long)KEY_INF);
-        const uint32_t tile = tile0 + i;
-        if (i < tpb && tile < n_tiles) {                               /* uniform */
-            const bool more = i + 1 < tpb && tile + 1 < n_tiles;
-            uint32_t par_next = 0, p_next = 0, off_next = 0;
+        if (i < tpb && slot0 + i < n_tiles) {                          /* uniform */
+            const bool more = i + 1 < tpb && slot0 + i + 1 < n_tiles;
+            uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0;
             if (more) {
-                par_next = bpar[tile + 1];
+                tile_next = tile_list ? tile_list[slot0 + i + 1] : tile + 1;
+                par_next = bpar[tile_next];
                 p_next = min(par_next + threadIdx.x, n_parent);
                 if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
             }
@@ -567,7 +613,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                         B.last_r[c] = ch.r; B.last_t[c] = ch.t; B.parent[c] = ch.parent;
                         B.count[c] = control_count(P, ch.r, ch.t);        /* its children-to-be, for the next level's scan */
                         const double *cn = cpL + (level + 1) * CP_STRIDE;   /* (rows past the problem's depth are never read back) */
-                        B.margin[c] = level + 1 < P.depth ? node_margin(P, cn[6], cn[7], ch.s.x, ch.s.y, ch.s.v, ch.s.rpm) : 0.0f;
+                        B.margin[c] = level + 1 < P.depth ? node_margin(P, cn[6], cn[7], ch.s.x, ch.s.y, ch.s.v, ch.s.rpm, ch.s.sh, ch.s.ch) : 0.0f;
                     }
                     kc = key_of(ch.score);
                     keys[i] = __longlong_as_double((long long)kc);
@@ -578,10 +624,10 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
             if (more) {
                 if (threadIdx.x < PARENT_WINDOW) {
                     win[(i + 1) & 1][threadIdx.x] = off_next;
-                    if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile + 2) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
+                    if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
                 }
                 if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
-                par0 = par_next;
+                par0 = par_next; tile = tile_next;
                 __syncthreads();
             }
         }
@@ -653,7 +699,8 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
                                         int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
                                         const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
                                         const uint32_t *__restrict__ pcnt, uint32_t nblk, const uint32_t *__restrict__ bpar,
-                                        uint64_t *__restrict__ out, TreeFinishLds &S)
+                                        uint64_t *__restrict__ out, TreeFinishLds &S,
+                                        const uint32_t *__restrict__ tile_list = nullptr, uint32_t n_list = 0)
 {
     double *lds = S.lds;
     uint64_t *s_list = S.s_list, *red = S.red, *s_win = S.s_win;
@@ -709,9 +756,10 @@ __device__ inline void tree_finish_body(const DevProblem *__restrict__ probs, co
     /* those workgroups' children once more, a lane per child and 256 lanes per tile, to see which of them are near */
     const LevelPtrs A = levels[L];
     for (uint32_t b = threadIdx.x >> 8; b < min(s_nb, 256u) * tpb; b += blockDim.x >> 8) {
-        const uint32_t tile = s_blocks[b / tpb] * tpb + b % tpb;
+        const uint32_t slot = s_blocks[b / tpb] * tpb + b % tpb;      /* as the expansion's workgroup numbered its tiles */
+        const uint32_t tile = tile_list ? tile_list[min(slot, n_list - 1)] : slot;
         const uint32_t c = tile * 256 + (threadIdx.x & 255);
-        if (c < n_child) {
+        if ((!tile_list || slot < n_list) && c < n_child) {
             const uint32_t par = find_parent_from(A.offset, bpar[tile], n_parent, c);
             const FastChild ch = make_child_fast(P, cpL, subL, A, par, c - A.offset[par], L);
             if (ch.score <= limit) {
@@ -757,10 +805,11 @@ __global__ __launch_bounds__(TREE_FINISH_THREADS) void tree_finish_kernel(const 
                                                           int L, uint32_t n_parent, uint32_t n_child, double refine_rel, uint32_t tpb,
                                                           const uint64_t *__restrict__ pkey, const uint64_t *__restrict__ pord,
                                                           const uint32_t *__restrict__ pcnt, uint32_t nblk,
-                                                          const uint32_t *__restrict__ bpar, uint64_t *__restrict__ out)
+                                                          const uint32_t *__restrict__ bpar, uint64_t *__restrict__ out,
+                                                          const uint32_t *__restrict__ tile_list, uint32_t n_list)
 {
     __shared__ __attribute__((aligned(16))) TreeFinishLds S;
-    tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, bpar, out, S);
+    tree_finish_body(probs, levels, L, n_parent, n_child, refine_rel, tpb, pkey, pord, pcnt, nblk, bpar, out, S, tile_list, n_list);
 }
 
 /* ---- the blind shallow levels --------------------------------------------------------------------------------
@@ -856,14 +905,23 @@ __global__ __launch_bounds__(64) void path_trace_kernel(const DevProblem *__rest
 
 /* stage 1: (key, ordinal) of the level; stage 2 (a second launch, after leaf_record_kernel where the level was not
  * stored): the winner's cumulative and last-step score from its record (slot `o`, or slot 0 of a one-node buffer) */
-__global__ __launch_bounds__(256) void level_reduce_kernel(const DevProblem *__restrict__ probs, const uint64_t *__restrict__ pkey,
+__global__ __launch_bounds__(TREE_FINISH_THREADS) void level_reduce_kernel(const DevProblem *__restrict__ probs, const uint64_t *__restrict__ pkey,
                                                            const uint64_t *__restrict__ pord, const uint64_t *__restrict__ pkey2,
                                                            uint32_t nblk, uint64_t *__restrict__ out)
 {
-    __shared__ uint64_t red[8];
+    __shared__ uint64_t red[32];
     __shared__ uint64_t s_o;
     uint64_t k = ~0ull, o = ~0ull;
-    for (uint32_t j = threadIdx.x; j < nblk; j += blockDim.x) lex_min(k, o, pkey[j], pord[j]);
+    for (uint32_t j0 = threadIdx.x; j0 < nblk; j0 += 8 * blockDim.x) {
+        uint64_t kk[8], oo[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = j0 + u * blockDim.x;
+            kk[u] = j < nblk ? pkey[j] : ~0ull; oo[u] = j < nblk ? pord[j] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) lex_min(k, o, kk[u], oo[u]);
+    }
     block_argmin(k, o, red);
     if (threadIdx.x == 0) { out[0] = k; out[1] = o; s_o = o; }
     __syncthreads();
@@ -915,6 +973,45 @@ __global__ void trace_all_kernel(const LevelPtrs *__restrict__ levels, LevelPtrs
     }
 }
 
+/* ---- the final level's short list -------------------------------------------------------------------------------
+ * Of a wide final level nearly every tile lies out of reach of its checkpoint (97.6 % of the 1.2e6 tiles of the depth-7
+ * semicircle tree) -- once a bound is known.  So: (1) the tiles that hold the children of ONE promising node (the level
+ * above's winner) are expanded first, which leaves a bound behind; (2) tile_select_kernel lists the tiles that bound
+ * does not exclude; (3) the expansion runs over the list only, and goes on tightening the bound and skipping as before.
+ * Which tiles are listed changes no result: an excluded tile holds no leaf within the near-tie window of any score
+ * already seen, let alone of the level's minimum. */
+__global__ void seed_tiles_kernel(LevelPtrs A, uint32_t node, uint32_t *__restrict__ list)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const uint32_t a = A.offset[node], b = A.offset[node + 1];
+    list[0] = a >> 8; list[1] = (max(b, a + 1) - 1) >> 8;
+}
+
+/* 256 tiles per workgroup: their parents are consecutive nodes; every node lowers the margin of the (one or two) tiles
+ * its children fall into, then a lane per tile decides */
+__global__ __launch_bounds__(256) void tile_select_kernel(LevelPtrs A, uint32_t n_parent, const uint32_t *__restrict__ bpar,
+                                                          uint32_t n_tiles, const uint64_t *bound, uint32_t *__restrict__ list,
+                                                          uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t s_m[256];                                    /* bits of non-negative floats order like the floats */
+    const uint32_t t0 = blockIdx.x * 256, nt = min(256u, n_tiles - t0);
+    s_m[threadIdx.x] = 0x7F800000u;
+    __syncthreads();
+    const uint32_t p_lo = bpar[t0], p_hi = t0 + nt < n_tiles ? min(bpar[t0 + nt] + 1, n_parent) : n_parent;
+    for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += 256) {
+        const uint32_t a = A.offset[p], b = A.offset[p + 1];
+        if (b <= a) continue;
+        const uint32_t bits = __float_as_uint(fmaxf(A.margin[p], 0.0f));
+        const uint32_t ta = max(a >> 8, t0), tb = min((b - 1) >> 8, t0 + nt - 1);
+        for (uint32_t t = ta; t <= tb; t++) atomicMin(&s_m[t - t0], bits);
+    }
+    __syncthreads();
+    if (threadIdx.x < nt && !margin_beyond(__uint_as_float(s_m[threadIdx.x]), tree_bound_read(bound)))
+        list[atomicAdd(count, 1u)] = t0 + threadIdx.x;
+}
+
+#define TILE_LIST_MIN 8192u      /* tiles (2.1e6 leaves) from which a final level is worth the list's two launches and one read-back */
+
 /* ---- host ------------------------------------------------------------------------------------------------------ */
 static void free_level(TreeLevelBuf &b)
 {
@@ -932,6 +1029,7 @@ void mpc_tree_free(mpc_hip_handle *h)
     (void)hipFree(h->d_scan_tmp); h->d_scan_tmp = nullptr; h->cap_scan_tmp = 0;
     (void)hipFree(h->d_level_ptrs); h->d_level_ptrs = nullptr;
     (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
+    (void)hipFree(h->d_tile_list); h->d_tile_list = nullptr; h->cap_tile_list = 0;
     (void)hipFree(h->d_tree_meta); h->d_tree_meta = nullptr;
     (void)hipHostFree(h->h_tree_meta); h->h_tree_meta = nullptr;
 }
@@ -1073,17 +1171,17 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             TreeLevelBuf &A = h->tree[it], &B = h->tree[it + 1];
             if (fast) {
                 if (stored) hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                               (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp, d_bound);
+                                               (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp, d_bound, (const uint32_t *)nullptr, 0u);
                 else hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                        (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp, d_bound);
+                                        (uint32_t)cb, it, (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, mp, d_bound, (const uint32_t *)nullptr, 0u);
                 hipLaunchKernelGGL(tree_post_kernel<true>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
                                    (double)MPC_REFINE_REL, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_pkey2, h->d_winners, h->d_tree_meta,
                                    (int)(stored && it + 1 < blind), h->d_bpar);
             } else {
                 if (stored) hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                               (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp, d_bound);
+                                               (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp, d_bound, (const uint32_t *)nullptr, 0u);
                 else hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)pb, h->d_bpar, ptrs(B),
-                                        (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp, d_bound);
+                                        (uint32_t)cb, it, 1u, h->d_pkey, h->d_pord, h->d_pkey2, mp, d_bound, (const uint32_t *)nullptr, 0u);
                 hipLaunchKernelGGL(tree_post_kernel<false>, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_level_ptrs, it, (int)stored,
                                    0.0, 1u, h->d_pkey, h->d_pord, h->d_pcnt, h->d_pkey2, h->d_winners, h->d_tree_meta,
                                    (int)(stored && it + 1 < blind), h->d_bpar);
@@ -1159,27 +1257,62 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         }
         B.n = nchild;
         if (int s = publish_level(h, it + 1)) return s;
-        const uint32_t n_tiles = (nchild + 255) / 256;
+        uint32_t n_tiles = (nchild + 255) / 256;
+        if (int s = mpc_ensure_partials(h, (n_tiles + EXPAND_TILES - 1) / EXPAND_TILES + 4096)) return s;
+        /* a wide final level: the short list of its tiles (seed_tiles_kernel / tile_select_kernel above) */
+        const uint32_t *d_list = nullptr;
+        /* diagnostic, with MPC_HIP_TREE_SYNC_LEVELS: the list from this many tiles on (1: for every final level -- how the
+         * random runs of tools/fuzz_tree.py reach this path with their shallow trees) */
+        static const uint32_t list_min = getenv("MPC_HIP_TREE_LIST_MIN") ? (uint32_t)strtoul(getenv("MPC_HIP_TREE_LIST_MIN"), nullptr, 10) : TILE_LIST_MIN;
+        if (!stored && n_tiles >= list_min) {
+            if ((size_t)n_tiles + 4 > h->cap_tile_list) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                (void)hipFree(h->d_tile_list); h->d_tile_list = nullptr; h->cap_tile_list = 0;
+                HIP_TRY(hipMalloc(&h->d_tile_list, sizeof(uint32_t) * ((size_t)n_tiles + 4)));
+                h->cap_tile_list = (size_t)n_tiles + 4;
+            }
+            /* the node whose children go first: the level above's winner where this shard holds it, else the middle one */
+            const uint64_t lead = completed == it && best_leaf >= A.first && best_leaf - A.first < n ? best_leaf - A.first : n / 2;
+            HIP_TRY(hipMemsetAsync(h->d_tile_list, 0, sizeof(uint32_t), h->stream));
+            hipLaunchKernelGGL(seed_tiles_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(A), (uint32_t)lead, h->d_tile_list + 1);
+            if (fast)
+                hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(1), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
+                                   nchild, it, (double)MPC_REFINE_REL, 2u, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
+                                   (const uint32_t *)h->d_tile_list + 1, 2u);
+            else
+                hipLaunchKernelGGL(expand_kernel<false>, dim3(1), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
+                                   2u, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, (const uint32_t *)h->d_tile_list + 1, 2u);
+            hipLaunchKernelGGL(tile_select_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, ptrs(A), n, h->d_bpar, n_tiles,
+                               (const uint64_t *)d_bound, h->d_tile_list + 4, h->d_tile_list);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_tile_list, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            uint32_t listed = 0;
+            memcpy(&listed, h->h_pair, sizeof listed);
+            if (listed > 0 && listed <= n_tiles) { d_list = h->d_tile_list + 4; n_tiles = listed; }      /* (0: cannot happen -- the seed's own tile is listed) */
+        }
         const uint32_t tpb = std::min<uint32_t>(EXPAND_TILES, std::max<uint32_t>(1, n_tiles / 4096));   /* >= 4096 workgroups first */
         const uint32_t nblk = (n_tiles + tpb - 1) / tpb;
         if (int s = mpc_ensure_partials(h, nblk)) return s;
         if (fast) {
             if (stored)
                 hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
+                                   (const uint32_t *)nullptr, 0u);
             else
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
-                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound);
+                                   nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
+                                   d_list, n_tiles);
             hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(TREE_FINISH_THREADS), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
-                               (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_bpar, h->d_winners);
+                               (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_bpar, h->d_winners, d_list, n_tiles);
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, (const uint32_t *)nullptr, 0u);
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound);
-            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_probs, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, d_list, n_tiles);
+            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(TREE_FINISH_THREADS), 0, h->stream, h->d_probs, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
             if (!stored)
                 hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
             hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);

@@ -46,6 +46,19 @@ def test_tree_slice_with_random_hulls(solver):
     print("tree slice, random hulls: 150 problems, flagged libm ties:", len(out["libm_ties"]), "worst level-score error %.3g" % out["worst"])
 
 
+def test_tree_slice_through_the_final_levels_short_list():
+    """a wide final level is expanded from a short list of its tiles (mpc_tree.hip: tile_select_kernel); the random trees are
+    too shallow to be wide, so a child process runs 120 of them (random boats) with the library's diagnostic switches that
+    send every level the synchronised way and every final level through the list"""
+    import subprocess
+    env = dict(os.environ, MPC_HIP_TREE_SYNC_LEVELS="1", MPC_HIP_TREE_LIST_MIN="1")
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "fuzz_tree.py"), "120", "20267", "hulls"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("tree problems")]
+    assert summary and "tree problems 120 ; disagreements WITHOUT the libm_tie flag 0 ;" in summary[0], r.stdout[-3000:]
+
+
 def test_explicit_slice(solver):
     import fuzz_explicit
     out = fuzz_explicit.run(200, seed=20264, solver=solver, verbose=False, sizes=(1, 63, 64, 65, 300, 1000))
