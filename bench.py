@@ -97,7 +97,8 @@ def tree_block(M, W, device, with_cpu):
     solver.set_timing(0)
     out = {"note": "p50 wall ms of one synchronous mpc_hip_solve_tree call (host -> C-ABI -> result filled); strict = the reference's "
                    "arithmetic expands the tree, fast = the streamlined model expands and the strict one decides; cpu = the oracle's DFS "
-                   "restatement on one host thread (the whole deepening loop to that depth)",
+                   "restatement on one host thread (the whole deepening loop to that depth); simulate_calls = nodes of the tree as "
+                   "the reference walks them -- on the last level the library simulates only nodes that can still win (same result)",
            "budget_s": 0.1, "scenarios": {}}
     scenarios = {"lrl_semicircle": lambda d: W.semicircle_problem(d + 1.5)[0],
                  "config1_straight_line": lambda d: W.config1_problem(depth=d)[0]}

@@ -350,10 +350,13 @@ void mpc_pack_problem(const mpc_problem *p, uint64_t seed, const Model &model, D
         d->reach_t = level_time * (1.0 + 1.0e-6);
         d->reach_acc = 0.5 * d->reach_dv * (level_time + dt_max) * (1.0 + 1.0e-6);
         /* the heading turns at rudder_coefficient * max(sqrt(prop speed), v) * sin(rudder angle) / rudder_distance
-         * (VehicleState.h:122-128), |rudder angle| <= |max_rudder_angle| <= pi/2 */
-        d->reach_yaw = fabs(model.rudder_coefficient / model.rudder_distance) * sin(fabs(model.max_rudder_angle)) * level_time * (1.0 + 1.0e-6);
+         * (VehicleState.h:122-128), |rudder angle| <= |max_rudder_angle| <= pi/2: while v stays below sqrt(C R), by at most
+         * D = that rate at sqrt(C R) times the level's length */
         d->reach_sqrtps = sqrt(fabs(ps));
-        d->reach_pad = 0;
+        const double turn = fabs(model.rudder_coefficient / model.rudder_distance) * sin(fabs(model.max_rudder_angle)) * d->reach_sqrtps *
+                            level_time * (1.0 + 1.0e-6) + 1.0e-6;
+        d->reach_sd = turn < 1.5 ? sin(turn) : 1.0;
+        d->reach_cd = turn < 1.5 ? cos(turn) : -1.0;
         d->reach_vcap = ok && isfinite(d->reach_dv) && isfinite(vcap) ? vcap : -1.0;
         d->reach_rpm = R;
         d->reach_cx = p->current_x * level_time; d->reach_cy = p->current_y * level_time;

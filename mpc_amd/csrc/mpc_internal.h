@@ -30,10 +30,11 @@ struct DevProblem {
     int32_t pad0; double pad1;   /* keeps cp 16-byte aligned for the staging vectors */
     /* How far a node can travel through the water in one level (mpc_pack_problem derives it from the hull and the schedule;
      * the tree search's final level leaves out parents none of whose children can come near enough to win, mpc_tree.hip):
-     * a node with 0 <= v, v + reach_dv <= reach_vcap and |rpm| <= reach_rpm moves at most v * reach_t + reach_acc, and its
-     * heading turns by at most reach_yaw * max(reach_sqrtps, v + reach_dv).  reach_vcap < 0: no such bound for this
-     * hull / schedule. */
-    double reach_dv, reach_t, reach_vcap, reach_rpm, reach_cx, reach_cy, reach_acc, reach_yaw, reach_sqrtps, reach_pad;
+     * a node with 0 <= v, v + reach_dv <= reach_vcap and |rpm| <= reach_rpm moves at most v * reach_t + reach_acc, and
+     * while v + reach_dv <= reach_sqrtps (the propeller wash, not the hull's speed, is what the rudder works in) its
+     * heading turns by at most D, given as reach_sd = sin D, reach_cd = cos D (D >= pi/2: reach_cd < 0, no statement).
+     * reach_vcap < 0: no such bound for this hull / schedule. */
+    double reach_dv, reach_t, reach_vcap, reach_rpm, reach_cx, reach_cy, reach_acc, reach_sqrtps, reach_sd, reach_cd;
     mpc::Model model;            /* this problem's hull (mpc_hip_set_model; VehicleState.h:86-101) */
     double cp[MPC_MAX_DEPTH * CP_STRIDE];
     double sub[MPC_MAX_SUBSTEPS * SUB_STRIDE];

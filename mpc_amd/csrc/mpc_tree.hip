@@ -200,7 +200,7 @@ __device__ inline void tree_bound_offer(uint64_t *bound, uint64_t seen, uint64_t
  * in the frame the node's position is held in -- moved back by the current's drift over the level where the frame is the
  * ground's; (ux, uy) = (sin, cos) of the node's heading, any length.
  *   Through the water a child ends at p + sum v' dt (sin h, cos h) with 0 <= v', sum v' dt <= s = v0 T + a T (T + dt) / 2 and
- *   |h - h0| <= D = the most the rudder can turn the vessel in a level (DevProblem.reach_*, mpc_pack_problem): a positive
+ *   |h - h0| <= D = the most the rudder can turn the vessel in a level (DevProblem.reach_sd / _cd, mpc_pack_problem): a positive
  *   combination of unit vectors within D of the heading, so the end point lies in the circular sector of radius s and
  *   half-angle D about the heading (D < pi/2; a disc otherwise).  The margin is the checkpoint's distance to that sector.
  * Rounded down to a float; 0 = no statement: a NaN state, a node moving astern, a hull without a reach bound, a
@@ -213,27 +213,27 @@ __device__ inline float node_margin(const DevProblem &P, double gx, double gy, d
     const double ex = gx - px, ey = gy - py;
     const double d = sqrt(fma(ex, ex, ey * ey));
     const double s = fma(v0, P.reach_t, P.reach_acc) + 1.0e-6;
-    double m = d - s;                                                    /* the disc */
-    const double D = fma(P.reach_yaw, fmax(P.reach_sqrtps, V), 1.0e-6);
-    const double un = sqrt(fma(ux, ux, uy * uy)) * d;
-    if (D < 1.5 && un > 0.0) {
-        const double cf = fma(ex, ux, ey * uy) / un, sf = fabs(fma(ex, uy, -(ey * ux))) / un;   /* angle checkpoint / heading */
-        double sD, cD;
-        sincos(D, &sD, &cD);
-        if (cf < cD) {                                                   /* outside the sector's angle: its edge decides */
-            const double cq = fma(cf, cD, sf * sD), sq = fma(sf, cD, -(cf * sD));              /* angle to the nearer edge */
-            const double along = d * cq, perp = d * fmax(sq, 0.0);
-            m = cq <= 0.0 ? d : (along <= s ? perp : sqrt(fma(along - s, along - s, perp * perp)));
-        }
+    /* the checkpoint in the heading's frame: along = d cos(angle to the heading), side = d |sin| of it */
+    const double iu = rsqrt(fma(ux, ux, uy * uy));
+    const double along = fma(ex, ux, ey * uy) * iu, side = fabs(fma(ex, uy, -(ey * ux))) * iu;
+    const double cD = P.reach_cd, sD = P.reach_sd;
+    double m = d - s;                                                    /* the disc; inside the sector's angle: its arc */
+    if (cD >= 0.0 && V <= P.reach_sqrtps && along < cD * d) {            /* outside the angle: the sector's nearer edge decides */
+        const double a = fma(along, cD, side * sD), p = fmax(fma(side, cD, -(along * sD)), 0.0);   /* along / across that edge */
+        m = a <= 0.0 ? d : (a <= s ? p : sqrt(fma(a - s, a - s, p * p)));
     }
     m = m * (1.0 - 1.0e-9) - 1.0e-6;
-    return bounded && m > 0.0 ? __double2float_rd(m) : 0.0f;
+    return bounded && m > 0.0 ? __double2float_rd(m) : 0.0f;             /* (NaN anywhere: 0) */
 }
 
 __device__ inline float strict_node_margin(const DevProblem &P, const double *cp_next, const Veh &s)
 {
     double sh, ch;
+#if defined(__HIP_DEVICE_COMPILE__)
+    heading_sincos(s.h, sh, ch);                                        /* (headings are in [0, 2 pi): estimate()'s fmod) */
+#else
     sincos(s.h, &sh, &ch);
+#endif
     return node_margin(P, cp_next[0] - P.reach_cx, cp_next[1] - P.reach_cy, s.x, s.y, s.v, s.rpm, sh, ch);
 }
 

@@ -13,12 +13,17 @@ PEAK = 78.6e12
 SIMDS = 1024
 
 
-def counters(d, kernel):
-    acc = defaultdict(lambda: [0.0, 0])
+def counters(d, kernel, largest_grid_only=False):
+    """mean per launch; largest_grid_only: over the launches with the kernel's largest grid only (the tree: one level)"""
+    rows = []
     for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(path)):
-            if kernel in r["Kernel_Name"]:
-                acc[r["Counter_Name"]][0] += float(r["Counter_Value"]); acc[r["Counter_Name"]][1] += 1
+        rows += [r for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"]]
+    if largest_grid_only and rows:
+        g = max(int(r["Grid_Size"]) for r in rows)
+        rows = [r for r in rows if int(r["Grid_Size"]) == g]
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in rows:
+        acc[r["Counter_Name"]][0] += float(r["Counter_Value"]); acc[r["Counter_Name"]][1] += 1
     return {k: s / n for k, (s, n) in acc.items()}
 
 
@@ -32,7 +37,7 @@ def stats(d, kernel, pick=max):
 
 
 def report(title, d, kernel, units, unit_name, flop_per_unit, pmc_launch_is_max):
-    c = counters(d, kernel)
+    c = counters(d, kernel, pmc_launch_is_max)
     ns, calls = stats(d, kernel, max if pmc_launch_is_max else None)
     print("## " + title)
     print("# kernel-trace: %s = %.1f us (%d launches in the trace)" % ("largest launch" if pmc_launch_is_max else "average launch", ns / 1e3, calls))
@@ -60,14 +65,21 @@ def report(title, d, kernel, units, unit_name, flop_per_unit, pmc_launch_is_max)
 
 if which == "tree":
     print("# rocprofv3 --pmc <one set per run> -- python3 tools/gpu_probe_tree_level.py fast|strict 7 2   (tools/collect_profiles_tree.sh; MI355X)")
-    print("# The LRL-semicircle tree of test_controller.cpp:449-467 to depth 7: the last level has 303,370,833 leaves, each one")
-    print("# simulate(r, t, 1.0) = 11 Euler substeps + one compareStates; counters are the mean over the probe's two depth-7 launches")
-    print("# of the <false> kernels (the unstored final level, 94 % of the tree).  Algorithmic work per leaf: 11 x 54 + 21 = 615 FLOP.")
+    print("# The LRL-semicircle tree of test_controller.cpp:449-467 to depth 7.  Each node is simulate(r, t, 1.0) = 11 Euler substeps")
+    print("# + one compareStates: 11 x 54 + 21 = 615 FLOP.  Counters: mean over the probe's launches with the kernel's largest grid.")
     print("# SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles.")
+    print("#")
+    print("# <true> kernels = a STORED level: every child simulated and written (level 6: 17,827,584 nodes) -- the kernels' plain rate.")
+    print("# <false> kernels = the FINAL level (303,370,833 leaves), which is searched, not enumerated: the launch runs over the short")
+    print("# list of tiles within reach of the checkpoint (tile_select_kernel) and skips waves that cannot win; its 'algorithmic'")
+    print("# lines below price the reference's full enumeration of that level against the time this launch took -- an equivalent")
+    print("# rate, not arithmetic the GPU performed (the hardware-counted line is what it performed).")
     print()
-    report("expand_fast_kernel<false> (MPC_PREC_FAST expansion: what the drop-in runs from depth 6 on)", src + "/tree_fast", "expand_fast_kernel<false>",
+    report("expand_fast_kernel<true> (MPC_PREC_FAST, stored level 6)", src + "/tree_fast", "expand_fast_kernel<true>", 17827584, "node", 615, True)
+    report("expand_kernel<true> (MPC_PREC_F64, stored level 6)", src + "/tree_strict", "expand_kernel<true>", 17827584, "node", 615, True)
+    report("expand_fast_kernel<false> (MPC_PREC_FAST, final level 7, short list)", src + "/tree_fast", "expand_fast_kernel<false>",
            303370833, "leaf", 615, True)
-    report("expand_kernel<false> (MPC_PREC_F64 expansion: the reference's arithmetic)", src + "/tree_strict", "expand_kernel<false>",
+    report("expand_kernel<false> (MPC_PREC_F64, final level 7, short list)", src + "/tree_strict", "expand_kernel<false>",
            303370833, "leaf", 615, True)
 else:
     print("# rocprofv3 --pmc <one set per run> -- python3 bench.py --precision f64 --no-pipeline --steps 20 --warmup 5 ...   (tools/collect_profiles_tree.sh; MI355X)")
