@@ -89,7 +89,7 @@ def cpu_baseline_tree(problem, depth):
 
 def tree_block(M, W, device, with_cpu):
     """The PRODUCTION path in the bench line: the reference-native limited-branching tree search exactly as the drop-in
-    runs it (mpc_hip_solve_tree through the C-ABI, one synchronous solve at a time, problem upload and result copy
+    runs it (mpc_hip_solve_tree / _deep through the C-ABI, one synchronous solve at a time, problem upload and result copy
     included), on the reference's own end-to-end scenario (LRL semicircle, test_controller.cpp:449-467) and on BASELINE
     config 1's straight line: p50 wall per depth for both expansions, the deepest level completed inside the reference's
     0.1-s planning budget (controller.h:153), and beside them the oracle's single-thread time and choice."""
@@ -104,18 +104,20 @@ def tree_block(M, W, device, with_cpu):
                  "config1_straight_line": lambda d: W.config1_problem(depth=d)[0]}
     for name, make in scenarios.items():
         rows = {}
-        for depth in (3, 4, 5, 7):
+        for depth in (3, 4, 5, 7, 8):
             p = make(depth)
             assert p.depth == depth, (name, depth, p.depth)
             row = {}
             chosen = {}
+            # depth 8 (5.2e9 leaves) is beyond one expansion: mpc_hip_solve_tree_deep, what the drop-in calls, searches it in pieces
+            solve = solver.solve_tree_deep if depth > 7 else solver.solve_tree
             for label, prec in (("strict", M.PREC_F64), ("fast", M.PREC_FAST)):
-                reps = 40 if depth <= 5 else 7
-                solver.solve_tree(p, depth, precision=prec)                 # warm: buffers grown, code objects loaded
+                reps = 40 if depth <= 5 else (7 if depth <= 7 else 3)
+                solve(p, depth, precision=prec)                             # warm: buffers grown, code objects loaded
                 lat = []
                 for _ in range(reps):
                     a = time.perf_counter()
-                    res, levels = solver.solve_tree(p, depth, precision=prec)
+                    res, levels = solve(p, depth, precision=prec)
                     lat.append((time.perf_counter() - a) * 1e3)
                 row[label + "_p50_ms"] = float(np.median(lat))
                 chosen[label] = (res.first_rudder, res.first_throttle, int(res.best_ordinal), int(res.levels), int(res.libm_tie))
@@ -139,7 +141,7 @@ def tree_block(M, W, device, with_cpu):
             got = []
             for _ in range(3):
                 t0 = time.perf_counter()
-                res, _ = solver.solve_tree(p8, 8, precision=prec, now=time.perf_counter, end_time=t0 + 0.1)
+                res, _ = solver.solve_tree_deep(p8, 8, precision=prec, now=time.perf_counter, end_time=t0 + 0.1)
                 got.append((int(res.levels), (time.perf_counter() - t0) * 1e3))
             deepest[label] = {"levels": min(g[0] for g in got), "wall_ms": float(np.median([g[1] for g in got]))}
         cpu_deepest = None

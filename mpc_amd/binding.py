@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "mpc_hip_substep_schedule", "mpc_hip_default_model", "mpc_hip_set_model", "mpc_hip_create", "mpc_hip_destroy", "mpc_hip_synchronize",
     "mpc_hip_eval_candidates", "mpc_hip_eval_seeded", "mpc_hip_eval_seeded_batch",
     "mpc_hip_upload_problems", "mpc_hip_upload_problems_from_plans", "mpc_hip_fetch_checkpoints", "mpc_hip_estimate_currents", "mpc_hip_history_reset", "mpc_hip_history_update", "mpc_hip_estimate_currents_resident", "mpc_hip_run_seeded", "mpc_hip_run_seeded_static", "mpc_hip_run_candidates", "mpc_hip_fetch_results",
-    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_combine_shards_exact", "mpc_hip_copy_winner_records", "mpc_hip_set_winner_record_sink", "mpc_hip_set_pipeline", "mpc_hip_flush", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_rollout",
+    "mpc_hip_device_winners", "mpc_hip_copy_winners", "mpc_hip_set_winner_sink", "mpc_hip_combine_shards", "mpc_hip_combine_shards_exact", "mpc_hip_copy_winner_records", "mpc_hip_set_winner_record_sink", "mpc_hip_set_pipeline", "mpc_hip_flush", "mpc_hip_set_timing", "mpc_hip_timing", "mpc_hip_solve_tree", "mpc_hip_solve_tree_shard", "mpc_hip_solve_tree_deep", "mpc_hip_rollout",
 )
 
 
@@ -158,6 +158,7 @@ def load_library(path=None):
     L.mpc_hip_solve_tree.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, C.POINTER(TreeLevel), RP]
     L.mpc_hip_solve_tree_shard.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, u64, i32, C.c_uint32, C.c_uint32,
                                            C.POINTER(TreeLevel), RP]
+    L.mpc_hip_solve_tree_deep.argtypes = [vp, PP, i32, i32, TIME_FN, vp, C.c_double, C.POINTER(TreeLevel), RP]
     L.mpc_hip_rollout.argtypes = [vp, PP, dp, dp, i32, RP]
     if path is None:
         _lib = L
@@ -441,6 +442,15 @@ class Solver:
             _check(self._L.mpc_hip_solve_tree_shard(self._h, C.byref(problem), max_levels, precision, cb, None,
                                                     float(end_time), max_nodes, split_level, shard, n_shards,
                                                     levels, C.byref(r)))
+        return r, levels
+
+    def solve_tree_deep(self, problem, max_levels, precision=PREC_F64, now=None, end_time=0.0):
+        """mpc_hip_solve_tree_deep: the plain search, then level by level in pieces beyond what one expansion holds"""
+        r = Result()
+        levels = (TreeLevel * max(max_levels, 1))()
+        cb = TIME_FN(lambda ctx: float(now())) if now is not None else C.cast(None, TIME_FN)
+        _check(self._L.mpc_hip_solve_tree_deep(self._h, C.byref(problem), max_levels, precision, cb, None, float(end_time),
+                                               levels, C.byref(r)))
         return r, levels
 
     def rollout(self, problem, rudders, throttles, precision=PREC_F64):

@@ -1085,6 +1085,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     h->tree[0].n = 1;
     if (int s = publish_level(h, 0)) return s;
 
+    h->tree_stopped_by_width = false;
     int completed = 0;
     uint64_t best_leaf = 0, steps = 0, evaluated = 0;
     bool leaf_stored = true, overflow = false, stop = false;
@@ -1244,7 +1245,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         /* a level wider than the caller's budget (or than 32-bit ordinals) ends the search like a deadline; one that is
          * only wider than the library's own storage cap is still expanded -- without stores, as the final level */
         const bool too_wide = tot[0] > max_nodes;
-        if (tot[1] != 0 || (too_wide && !own_cap)) break;
+        if (tot[1] != 0 || (too_wide && !own_cap)) { h->tree_stopped_by_width = true; break; }
         const uint32_t nchild = tot[0];
         TreeLevelBuf &B = h->tree[it + 1];
         /* the last level asked for is never a parent level: expanded without stores (strict: into a one-node buffer
@@ -1324,7 +1325,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
         record_level(it, nchild, h->h_pair, stored, h->h_pair[5]);
         if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
-        if (!stored) break;                                              /* nothing to expand the next level from */
+        if (!stored) { h->tree_stopped_by_width = too_wide; break; }     /* nothing to expand the next level from */
     }
     HIP_TRY(hipEventRecord(ev[1], h->stream));
     if (overflow) {
@@ -1426,4 +1427,89 @@ extern "C" int mpc_hip_solve_tree_shard(mpc_hip_handle *h, const mpc_problem *h_
 {
     return solve_tree_checked(h, h_problem, max_levels, precision, now, now_ctx, end_time, max_nodes, split_level, shard,
                               n_shards, h_level_best, h_result);
+}
+
+/* mpc_hip.h: the plain search, then one level at a time in pieces (this library's shards, one after the other on this
+ * handle) for as long as the clock and the levels asked for allow */
+extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
+                                       mpc_time_fn now, void *now_ctx, double end_time,
+                                       mpc_tree_level *h_level_best, mpc_result *h_result)
+{
+    if (!h || !h_problem || !h_result) { mpc_set_err("solve_tree_deep: NULL argument"); return MPC_ERR_INVALID; }
+    std::vector<mpc_tree_level> lv((size_t)std::max(max_levels, 1));
+    int s = solve_tree_checked(h, h_problem, max_levels, precision, now, now_ctx, end_time, 0, 0, 0, 1, lv.data(), h_result);
+    if (s != MPC_OK) return s;
+    int L = h_result->levels;
+    if (h_level_best) for (int l = 0; l < L; l++) h_level_best[l] = lv[(size_t)l];
+    const uint64_t nsub = (uint64_t)h_problem->n_substeps;
+    std::vector<mpc_tree_level> plv((size_t)std::max(max_levels, 1));
+    std::vector<mpc_result> keep(2);                          /* [0] the best piece so far, [1] the piece just searched */
+    while (L < max_levels && h->tree_stopped_by_width) {
+        if (now && now(now_ctx) >= end_time) break;
+        const int target = L + 1;
+        /* pieces: contiguous slices of a shallow level's nodes, so many that a piece's leaves fit 32-bit ordinals (<= 30
+         * children per node, a quarter of slack for uneven subtrees) and its slice of level L fits the storage cap */
+        const double leaves_L = (double)lv[(size_t)L - 1].n_leaves;
+        uint32_t pieces = (uint32_t)std::max(2.0, ceil(std::max(leaves_L * 30.0 * 1.25 / 4.0e9, leaves_L * 1.25 / (double)(1u << 28))));
+        bool done = false, abandoned = false;
+        for (int attempt = 0; attempt < 3 && !done && !abandoned; attempt++, pieces *= 2) {
+            int split = 1;
+            while (split < L - 1 && lv[(size_t)split - 1].n_leaves < 64ull * pieces) split++;
+            if (lv[(size_t)split - 1].n_leaves < pieces) { abandoned = true; break; }
+            uint64_t total = 0, best_key = ~0ull, best_ord = ~0ull, runner_up = ~0ull;
+            uint32_t tie = 0;
+            double k_ms = 0, t_ms = 0;
+            bool refit = false;
+            for (uint32_t piece = 0; piece < pieces; piece++) {
+                if (now && now(now_ctx) >= end_time) { abandoned = true; break; }    /* controller.cpp:101-103: an unfinished iteration does not count */
+                s = solve_tree_checked(h, h_problem, target, precision, now, now_ctx, end_time, 0, split, piece, pieces, plv.data(), &keep[1]);
+                if (s != MPC_OK) { abandoned = true; break; }
+                if (keep[1].levels < target) {                                        /* the clock, or a piece that still does not fit */
+                    if (h->tree_stopped_by_width && !(now && now(now_ctx) >= end_time)) refit = true; else abandoned = true;
+                    break;
+                }
+                const mpc_tree_level &t = plv[(size_t)target - 1];
+                uint64_t key;
+                memcpy(&key, &t.best_score, sizeof key);
+                if (!(t.best_score >= 0.0)) key = KEY_INF;
+                const uint64_t ord = total + t.best_leaf;
+                k_ms += keep[1].kernel_ms; t_ms += keep[1].total_ms;
+                if (key < best_key) {                                                 /* pieces come in DFS order: ties keep the first */
+                    runner_up = std::min(runner_up, best_key);
+                    best_key = key; best_ord = ord; tie = t.libm_tie;
+                    keep[0] = keep[1];
+                } else {
+                    runner_up = std::min(runner_up, key);
+                }
+                total += t.n_leaves;
+            }
+            if (abandoned) break;
+            if (refit) continue;
+            if (best_key >= KEY_INF) { abandoned = true; break; }
+            /* libm_tie of the whole level: the winner's own piece says so, or another piece's best lies as near */
+            if (runner_up < KEY_INF) {
+                double a, b;
+                memcpy(&a, &best_key, sizeof a); memcpy(&b, &runner_up, sizeof b);
+                if (b <= mpc_tie_limit(a, h_problem->w_distance, h_problem->w_heading, h_problem->w_speed)) tie = 1;
+            }
+            mpc_tree_level &out = lv[(size_t)target - 1];
+            out = plv[(size_t)target - 1];
+            out.n_leaves = total; out.best_leaf = best_ord; out.libm_tie = tie; out.reserved = 0;
+            out.best_score = keep[0].best_last; out.best_cumulative = keep[0].best_cumulative;
+            const uint64_t before = h_result->evaluated, steps_before = h_result->rollout_steps;
+            const double k0 = h_result->kernel_ms, t0 = h_result->total_ms;
+            *h_result = keep[0];
+            h_result->best_ordinal = best_ord;
+            h_result->levels = target;
+            h_result->libm_tie = tie;
+            h_result->evaluated = before + total; h_result->rollout_steps = steps_before + total * nsub;
+            h_result->kernel_ms = (float)(k0 + k_ms); h_result->total_ms = (float)(t0 + t_ms);
+            if (h_level_best) h_level_best[target - 1] = out;
+            L = target;
+            done = true;
+            h->tree_stopped_by_width = true;                                          /* the next level is wider still */
+        }
+        if (!done) break;
+    }
+    return MPC_OK;
 }

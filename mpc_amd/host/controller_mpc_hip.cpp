@@ -11,7 +11,7 @@
  *                                                        last controls (the reference re-reads the weights per node)
  *   :59-61  maxIterations                                same expression
  *   :96-98  sample the plan per deepening iteration      all maxIterations checkpoints sampled up front
- *   :80-189 iterative-deepening DFS                      mpc_hip_solve_tree (level-synchronous)
+ *   :80-189 iterative-deepening DFS                      mpc_hip_solve_tree_deep (level-synchronous)
  *   :83     cancellation poll per iteration              polled in the time callback, between levels
  *   :101    deadline poll per node                       polled between levels through the same callback
  *   :196-204 cleanup, displayTrajectory, finite check    same
@@ -184,7 +184,7 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
         Lease lease;
         /* Which model EXPANDS the tree; whichever it is, the strict model decides every level and the returned states
          * are the strict path's (same leaf, same bits: tests/test_gpu_tree.py).  The streamlined model is sooner from
-         * depth 6 on (depth 7: 7.7 ms against 18 ms), the strict one below (depth 4: 0.11 ms against 0.19 ms), so the
+         * depth 6 on (depth 7: 1.7 ms against 2.8 ms, depth 8: 23 ms against 44 ms), the strict one below (depth 4: 0.11 ms against 0.19 ms), so the
          * plan's length chooses; MPC_HIP_TREE_PRECISION=fast|strict (or f64) in the environment overrides. */
         static const int forced = [] {
             const char *e = getenv("MPC_HIP_TREE_PRECISION");
@@ -193,7 +193,9 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
             return -1;
         }();
         const int precision = forced >= 0 ? forced : (maxIterations > 5 ? (int)MPC_PREC_FAST : (int)MPC_PREC_F64);
-        status = mpc_hip_solve_tree(lease.h, &problem, maxIterations, precision, poll, &ctx, endTime, 0, nullptr, &result);
+        /* (the _deep entry point is mpc_hip_solve_tree for as long as one expansion holds a level -- depth 7 with the default
+         * control sets, ~2 ms -- and then goes on a level at a time in pieces while the clock allows: depth 8 in ~25 ms) */
+        status = mpc_hip_solve_tree_deep(lease.h, &problem, maxIterations, precision, poll, &ctx, endTime, nullptr, &result);
     }
     if (ctx.cancelled) return {};                                                             /* :83-86 */
     if (status == MPC_ERR_NO_ITERATION || status == MPC_ERR_NON_FINITE) {
@@ -210,7 +212,7 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
         throw std::runtime_error(mpc_hip_status_string(status));                              /* :196, :202 */
     }
     if (status != MPC_OK)
-        throw std::runtime_error(std::string("mpc_hip_solve_tree: ") + mpc_hip_status_string(status) + ": " + mpc_hip_last_error());
+        throw std::runtime_error(std::string("mpc_hip_solve_tree_deep: ") + mpc_hip_status_string(status) + ": " + mpc_hip_last_error());
 
     std::vector<State> forDisplay;                                                            /* :197-200 */
     forDisplay.reserve(result.levels + 1);

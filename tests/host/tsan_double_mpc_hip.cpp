@@ -116,6 +116,13 @@ int mpc_hip_solve_tree(mpc_hip_handle* h, const mpc_problem* p, int max_levels, 
     return MPC_OK;
 }
 
+/* (the drop-in calls the deepening entry point; to the double there is no level too wide for one search) */
+int mpc_hip_solve_tree_deep(mpc_hip_handle* h, const mpc_problem* p, int max_levels, int precision, mpc_time_fn now, void* ctx,
+                            double end_time, mpc_tree_level* levels, mpc_result* r)
+{
+    return mpc_hip_solve_tree(h, p, max_levels, precision, now, ctx, end_time, 0, levels, r);
+}
+
 /* how many handles the pool ever had checked out or parked at once: two overlapping solves need two, not more */
 int tsan_double_peak_handles(void) { return g_peak.load(); }
 

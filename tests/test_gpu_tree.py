@@ -343,6 +343,39 @@ def test_depth_8_as_the_8_shards_of_a_node(solver):
         assert s[depth].score - s[depth - 1].score >= res.best_last * (1 - 1e-10)
 
 
+@pytest.mark.parametrize("prec", [M.PREC_FAST, M.PREC_F64])
+def test_deepening_beyond_one_expansion_equals_the_shards(solver, prec):
+    """mpc_hip_solve_tree_deep: depth 8 (5.2e9 leaves: beyond 32-bit ordinals and the storage cap) on one handle, in pieces
+    -- the same winner, scores, trajectory and leaf count as the 8 shards of test_depth_8_as_the_8_shards_of_a_node
+    combined, the shallower levels those of the plain search; with a clock that runs out among the pieces the
+    unfinished level does not count (controller.cpp:101-103) and the result is the plain search's depth 7."""
+    import torch
+    from mpc_amd.distributed import tree_levels_tensor, combine_tree_levels
+    depth = 8
+    p, _plan = W.config1_problem(depth=depth)
+    plain, pl = solver.solve_tree(p, depth, precision=prec)
+    assert plain.status == 0 and plain.levels == 7                     # where one expansion ends
+    deep, dl = solver.solve_tree_deep(p, depth, precision=prec)
+    assert deep.status == 0 and deep.levels == 8
+    for l in range(7):
+        assert (dl[l].n_leaves, dl[l].best_leaf, dl[l].best_score, dl[l].libm_tie) == (pl[l].n_leaves, pl[l].best_leaf, pl[l].best_score, pl[l].libm_tie)
+    shards = [solver.solve_tree(p, depth, precision=prec, split_level=3, shard=s, n_shards=8) for s in range(8)]
+    total, ordinal, bits, owner = combine_tree_levels(torch.stack([tree_levels_tensor(lv, depth) for _, lv in shards]), 3)[-1]
+    assert (dl[7].n_leaves, dl[7].best_leaf) == (total, ordinal) and total == 5172889071
+    assert int(np.float64(dl[7].best_score).view(np.int64)) == bits
+    assert deep.best_ordinal == ordinal and deep.best_last == dl[7].best_score
+    assert traj_array(deep).tobytes() == traj_array(shards[owner][0]).tobytes()
+    assert deep.evaluated == sum(dl[l].n_leaves for l in range(8))
+    # the clock: 1 s per poll; the plain search polls a handful of times, the pieces' searches many more
+    t = [0.0]
+    def clock():
+        t[0] += 1.0
+        return t[0]
+    cut, cl = solver.solve_tree_deep(p, depth, precision=prec, now=clock, end_time=40.0)
+    assert cut.status == 0 and cut.levels == 7, (cut.levels, t[0])
+    assert traj_array(cut).tobytes() == traj_array(plain).tobytes() and cut.best_ordinal == plain.best_ordinal
+
+
 def _leaf_controls(p, depth):
     """every leaf of the depth-`depth` tree in DFS order (throttle outer, rudder inner: controller.cpp:174-182) as control
     sequences [depth][n_leaves]"""
