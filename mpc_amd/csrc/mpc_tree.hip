@@ -111,20 +111,22 @@ __global__ __launch_bounds__(256) void count_kernel(const DevProblem *__restrict
 
 __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *sh, uint32_t &total)
 {
-    /* Hillis-Steele over 256 threads in LDS */
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
-        const uint32_t a = (t >= d) ? sh[t - d] : 0;
-        __syncthreads();
-        sh[t] += a;
-        __syncthreads();
+    /* 256 threads = four wavefronts: a shuffle scan inside each (six steps, no LDS), the four wave totals through LDS --
+     * two barriers instead of the sixteen of a Hillis-Steele scan in LDS */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(x, d, 64);
+        if (lane >= d) x += up;
     }
-    total = sh[SCAN_BLOCK - 1];
-    const uint32_t ex = sh[t] - v;
+    if (lane == 63) sh[wave] = x;
     __syncthreads();
-    return ex;
+    const uint32_t t0 = sh[0], t1 = sh[1], t2 = sh[2], t3 = sh[3];
+    total = t0 + t1 + t2 + t3;
+    const uint32_t before = (wave > 0 ? t0 : 0) + (wave > 1 ? t1 : 0) + (wave > 2 ? t2 : 0);
+    __syncthreads();                                  /* sh may be rewritten by the caller's next scan */
+    return before + x - v;
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(const uint32_t *__restrict__ in, uint32_t n,
@@ -139,23 +141,25 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(const uint32_t *_
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-/* one block: exclusive scan of the tile sums in place; sums[nt] = grand total (as two words: lo, overflow flag) */
+/* one block: exclusive scan of the tile sums in place; sums[nt] = grand total (as two words: lo, overflow flag).
+ * SCAN_ITEMS consecutive sums per thread and trip (a 1e8-node level has 5e4 tile sums: 25 trips, not 200). */
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_top_kernel(uint32_t *__restrict__ sums, uint32_t nt)
 {
     __shared__ uint32_t sh[SCAN_BLOCK];
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nt; base += SCAN_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nt ? sums[i] : 0;
+    unsigned long long carry = 0;                          /* the same in every thread */
+    for (uint32_t base = 0; base < nt; base += SCAN_TILE) {
+        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = i0 + j < nt ? sums[i0 + j] : 0; s += v[j]; }
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, sh, total);
-        const unsigned long long c = carry;
-        if (i < nt) sums[i] = (uint32_t)(c + ex);
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
-        __syncthreads();
+        unsigned long long run = carry + block_exclusive_scan(s, sh, total);
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            if (i0 + j < nt) sums[i0 + j] = (uint32_t)run;
+            run += v[j];
+        }
+        carry += total;
     }
     if (threadIdx.x == 0) {
         sums[nt] = (uint32_t)(carry & 0xFFFFFFFFull);
