@@ -349,6 +349,8 @@ void mpc_pack_problem(const mpc_problem *p, uint64_t seed, const Model &model, D
         d->reach_dv = level_time * pc * ps * ps / model.mass * (1.0 + 1.0e-9);
         d->reach_t = level_time * (1.0 + 1.0e-6);
         d->reach_acc = 0.5 * d->reach_dv * (level_time + dt_max) * (1.0 + 1.0e-6);
+        d->reach_acc2 = d->reach_dv * (2.0 * level_time + dt_max) * (1.0 + 1.0e-6);      /* a 2T (2T + dt) / 2 */
+        d->reach_pad = 0;
         /* the heading turns at rudder_coefficient * max(sqrt(prop speed), v) * sin(rudder angle) / rudder_distance
          * (VehicleState.h:122-128), |rudder angle| <= |max_rudder_angle| <= pi/2: while v stays below sqrt(C R), by at most
          * D = that rate at sqrt(C R) times the level's length */

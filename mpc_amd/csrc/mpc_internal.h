@@ -35,6 +35,7 @@ struct DevProblem {
      * heading turns by at most D, given as reach_sd = sin D, reach_cd = cos D (D >= pi/2: reach_cd < 0, no statement).
      * reach_vcap < 0: no such bound for this hull / schedule. */
     double reach_dv, reach_t, reach_vcap, reach_rpm, reach_cx, reach_cy, reach_acc, reach_sqrtps, reach_sd, reach_cd;
+    double reach_acc2, reach_pad;   /* the same path bound over TWO levels: v * 2 reach_t + reach_acc2 (speed bound v + 2 reach_dv, turn 2 D) */
     mpc::Model model;            /* this problem's hull (mpc_hip_set_model; VehicleState.h:86-101) */
     double cp[MPC_MAX_DEPTH * CP_STRIDE];
     double sub[MPC_MAX_SUBSTEPS * SUB_STRIDE];
@@ -203,6 +204,7 @@ struct mpc_hip_handle {
     std::vector<TreeLevelBuf> tree;
     uint32_t *d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;
     uint32_t *d_bpar = nullptr; size_t cap_bpar = 0;              /* first parent of every 256-child workgroup */
+    double *d_tree_seed = nullptr;                                /* tree search: [0..1] seed bounds of the last two levels (ghost_select_kernel) */
     bool tree_stopped_by_width = false;                          /* the last tree search ended because the next level does not fit one expansion */
     uint32_t *d_tile_list = nullptr; size_t cap_tile_list = 0;   /* tree search, final level: [0] count, [1..2] seed tiles, [4..] the short list */
     LevelPtrs *d_level_ptrs = nullptr;                           /* [MPC_MAX_DEPTH + 2], fast-mode path walks */

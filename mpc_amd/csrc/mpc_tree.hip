@@ -209,20 +209,24 @@ __device__ inline void tree_bound_offer(uint64_t *bound, uint64_t seen, uint64_t
  *   half-angle D about the heading (D < pi/2; a disc otherwise).  The margin is the checkpoint's distance to that sector.
  * Rounded down to a float; 0 = no statement: a NaN state, a node moving astern, a hull without a reach bound, a
  * checkpoint within reach. */
+/* K = 2: the same over TWO levels -- (gx, gy) the checkpoint after the next one -- for the level above a final level
+ * (ghost_select_kernel): speed bound v0 + 2 a T, path v0 2T + a 2T (2T + dt) / 2, turn 2 D. */
+template <int K = 1>
 __device__ inline float node_margin(const DevProblem &P, double gx, double gy, double px, double py, double v0, double rpm0,
                                     double ux, double uy)
 {
-    const double V = v0 + P.reach_dv;
+    const double V = fma((double)K, P.reach_dv, v0);
     const bool bounded = v0 >= 0.0 && V <= P.reach_vcap && fabs(rpm0) <= P.reach_rpm;
     const double ex = gx - px, ey = gy - py;
     const double d = sqrt(fma(ex, ex, ey * ey));
-    const double s = fma(v0, P.reach_t, P.reach_acc) + 1.0e-6;
+    const double s = fma(v0, (double)K * P.reach_t, K == 1 ? P.reach_acc : P.reach_acc2) + 1.0e-6;
     /* the checkpoint in the heading's frame: along = d cos(angle to the heading), side = d |sin| of it */
     const double iu = rsqrt(fma(ux, ux, uy * uy));
     const double along = fma(ex, ux, ey * uy) * iu, side = fabs(fma(ex, uy, -(ey * ux))) * iu;
-    const double cD = P.reach_cd, sD = P.reach_sd;
+    const double c1 = P.reach_cd, s1 = P.reach_sd;
+    const double cD = K == 1 ? c1 : fma(c1, c1, -(s1 * s1)), sD = K == 1 ? s1 : 2.0 * s1 * c1;
     double m = d - s;                                                    /* the disc; inside the sector's angle: its arc */
-    if (cD >= 0.0 && V <= P.reach_sqrtps && along < cD * d) {            /* outside the angle: the sector's nearer edge decides */
+    if (c1 >= 0.0 && cD >= 0.0 && V <= P.reach_sqrtps && along < cD * d) {   /* outside the angle: the sector's nearer edge decides */
         const double a = fma(along, cD, side * sD), p = fmax(fma(side, cD, -(along * sD)), 0.0);   /* along / across that edge */
         m = a <= 0.0 ? d : (a <= s ? p : sqrt(fma(a - s, a - s, p * p)));
     }
@@ -241,8 +245,16 @@ __device__ inline float strict_node_margin(const DevProblem &P, const double *cp
     return node_margin(P, cp_next[0] - P.reach_cx, cp_next[1] - P.reach_cy, s.x, s.y, s.v, s.rpm, sh, ch);
 }
 
+#define MARGIN_GHOST __builtin_inff()
+
 /* the final level's tests: none of these nodes' children can end within dmax (NaN: no bound yet) of the checkpoint */
-__device__ inline bool margin_beyond(float margin, double dmax) { return margin > 0.0f && (double)margin >= dmax; }
+__device__ inline bool margin_beyond(float margin, double dmax) { return margin > 0.0f && ((double)margin >= dmax || margin == MARGIN_GHOST); }
+
+/* A GHOST is a node of the level above a final level that was given its place in the level (its child count, hence its
+ * children's ordinals) but never simulated: neither it nor any child of it can win (ghost_select_kernel).  Its margin says
+ * so -- +inf, beyond any bound, even none -- and nothing else of its record is ever written or may be read: whoever makes
+ * children from parents reports +inf for a ghost's. */
+__device__ inline bool is_ghost(const LevelPtrs &A, uint32_t par) { return A.margin[par] == MARGIN_GHOST; }
 
 /* wave 0 of a workgroup, all 64 lanes: the smallest margin among the parents of one tile (lane i holds parent par0 + i's
  * offset; parents whose children begin at or after tile_end, and lanes past the level, do not belong to the tile) */
@@ -279,7 +291,7 @@ __device__ inline Child make_child(const DevProblem &P, const double *cpL, const
         const bool far = dx * dx + dy * dy >= dmax * dmax;
         skip = __builtin_amdgcn_ballot_w64(!far) == 0;
     }
-    ch.score = skip ? __longlong_as_double((long long)KEY_INF) : strict_score(cp, ch.s, w);   /* :155 */
+    ch.score = skip || is_ghost(A, par) ? __longlong_as_double((long long)KEY_INF) : strict_score(cp, ch.s, w);   /* :155 */
     ch.cum = A.cum[par] + ch.score;                                                   /* :156 */
     ch.r = r; ch.t = t; ch.parent = par;                                              /* :152-153 (unclamped) */
     return ch;
@@ -363,14 +375,17 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
-    /* tile_list (the final level's short list, tile_select_kernel): the workgroup's tiles are entries of the list */
-    const uint32_t n_tiles = tile_list ? n_list : (n_child + 255) / 256;
+    /* tile_list, final level (!STORE): its short list (tile_select_kernel) -- the workgroup's tiles are entries of the list;
+     * stored level: one flag per tile, non-zero = a tile of ghosts (ghost_select_kernel) */
+    const uint32_t *list = STORE ? nullptr : tile_list, *ghost = STORE ? tile_list : nullptr;
+    const uint32_t n_tiles = list ? n_list : (n_child + 255) / 256;
     const uint32_t slot0 = blockIdx.x * tpb;
     if (slot0 >= n_tiles) {                                          /* uniform: a workgroup beyond the level */
         if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; pkey2[blockIdx.x] = ~0ull; }
         return;
     }
-    const uint32_t tile0 = tile_list ? tile_list[slot0] : slot0;
+    const uint32_t tile0 = list ? list[slot0] : slot0;
+    uint32_t ghost_tile = ghost ? ghost[tile0] : 0u;
     uint32_t par0 = bpar[tile0];                                     /* the parent of the tile's first child (scan_apply_kernel) */
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
@@ -383,10 +398,11 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     uint32_t tile = tile0;
     for (uint32_t i = 0; i < tpb && slot0 + i < n_tiles; i++) {
         const bool more = i + 1 < tpb && slot0 + i + 1 < n_tiles;
-        uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0;
+        uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0, ghost_next = 0;
         if (more) {                                                   /* in flight during this tile's arithmetic */
-            tile_next = tile_list ? tile_list[slot0 + i + 1] : tile + 1;
+            tile_next = list ? list[slot0 + i + 1] : tile + 1;
             par_next = bpar[tile_next];
+            ghost_next = ghost ? ghost[tile_next] : 0u;
             p_next = min(par_next + threadIdx.x, n_parent);
             if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
         }
@@ -395,7 +411,16 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
          * workgroup, so that leaving a tile out is a uniform decision: no parent of the tile has a child within reach */
         const double dmax = STORE ? 0.0 : s_dmax[i & 1];
         const bool skip_tile = !STORE && margin_beyond(s_margin[i & 1], dmax);
-        if (!skip_tile && c < n_child) {
+        if (STORE && ghost_tile) {                                    /* uniform: a place in the level, nothing else */
+            if (c < n_child) {
+                uint32_t first;
+                const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
+                double r, t;
+                control_pick(P, A.last_r[par], A.last_t[par], c - first, r, t);
+                B.count[c] = control_count(P, r, t);
+                B.margin[c] = MARGIN_GHOST;
+            }
+        } else if (!skip_tile && c < n_child) {
             uint32_t first;
             const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
             const Child ch = make_child<!STORE>(P, cpL, subL, A, par, c - first, level, dmax);
@@ -415,7 +440,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
                 if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
             }
             if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
-            par0 = par_next; tile = tile_next;
+            par0 = par_next; tile = tile_next; ghost_tile = ghost_next;
             __syncthreads();
         }
     }
@@ -509,7 +534,7 @@ __device__ inline FastChild make_child_fast(const DevProblem &P, const double *c
         const bool far = fma(ex, ex, ey * ey) >= dmax * dmax;          /* false for a NaN state and for "no bound yet" (NaN) */
         skip = __builtin_amdgcn_ballot_w64(!far) == 0;                 /* wave-uniform: every active lane is far */
     }
-    ch.score = skip ? __longlong_as_double((long long)KEY_INF) : fast_score<true>(cp, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
+    ch.score = skip || is_ghost(A, par) ? __longlong_as_double((long long)KEY_INF) : fast_score<true>(cp, ch.s, w, subL + (P.nsub - 1) * SUB_STRIDE);
     return ch;
 }
 
@@ -567,14 +592,17 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
-    /* tile_list (the final level's short list, tile_select_kernel): the workgroup's tiles are entries of the list */
-    const uint32_t n_tiles = tile_list ? n_list : (n_child + 255) / 256;
+    /* tile_list, final level (!STORE): its short list (tile_select_kernel) -- the workgroup's tiles are entries of the list;
+     * stored level: one flag per tile, non-zero = a tile of ghosts (ghost_select_kernel) */
+    const uint32_t *list = STORE ? nullptr : tile_list, *ghost = STORE ? tile_list : nullptr;
+    const uint32_t n_tiles = list ? n_list : (n_child + 255) / 256;
     const uint32_t slot0 = blockIdx.x * tpb;
     if (slot0 >= n_tiles) {
         if (threadIdx.x == 0) { pkey[blockIdx.x] = ~0ull; pord[blockIdx.x] = ~0ull; pcnt[blockIdx.x] = 0; }
         return;
     }
-    const uint32_t tile0 = tile_list ? tile_list[slot0] : slot0;
+    const uint32_t tile0 = list ? list[slot0] : slot0;
+    uint32_t ghost_tile = ghost ? ghost[tile0] : 0u;
     uint32_t par0 = bpar[tile0];
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
@@ -591,10 +619,11 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
         keys[i] = __longlong_as_double((long long)KEY_INF);
         if (i < tpb && slot0 + i < n_tiles) {                          /* uniform */
             const bool more = i + 1 < tpb && slot0 + i + 1 < n_tiles;
-            uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0;
+            uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0, ghost_next = 0;
             if (more) {
-                tile_next = tile_list ? tile_list[slot0 + i + 1] : tile + 1;
+                tile_next = list ? list[slot0 + i + 1] : tile + 1;
                 par_next = bpar[tile_next];
+                ghost_next = ghost ? ghost[tile_next] : 0u;
                 p_next = min(par_next + threadIdx.x, n_parent);
                 if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
             }
@@ -603,7 +632,16 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
              * workgroup, so that leaving a tile out is a uniform decision: no parent of the tile has a child within reach */
             const double dmax = STORE ? 0.0 : s_dmax[i & 1];
             const bool skip_tile = !STORE && margin_beyond(s_margin[i & 1], dmax);
-            if (!skip_tile) {
+            if (STORE && ghost_tile) {                                 /* uniform: a place in the level, nothing else */
+                if (c < n_child) {
+                    uint32_t first;
+                    const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
+                    double r, t;
+                    control_pick(P, A.last_r[par], A.last_t[par], c - first, r, t);
+                    B.count[c] = control_count(P, r, t);
+                    B.margin[c] = MARGIN_GHOST;
+                }
+            } else if (!skip_tile) {
                 const uint64_t seen = STORE ? 0 : tree_bound_key(bound);
                 uint64_t kc = ~0ull;
                 if (c < n_child) {
@@ -631,7 +669,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                     if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
                 }
                 if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
-                par0 = par_next; tile = tile_next;
+                par0 = par_next; tile = tile_next; ghost_tile = ghost_next;
                 __syncthreads();
             }
         }
@@ -1014,6 +1052,116 @@ __global__ __launch_bounds__(256) void tile_select_kernel(LevelPtrs A, uint32_t 
         list[atomicAdd(count, 1u)] = t0 + threadIdx.x;
 }
 
+/* ---- the level above a final level: ghosts ----------------------------------------------------------------------------
+ * When the level being expanded is the last one that will have children (the caller's max_levels says so), most of its
+ * nodes matter neither to its own record nor to the final level's: a parent whose children all end out of reach of this
+ * level's checkpoint AND whose grandchildren all end out of reach of the next one (node_margin over one and two levels,
+ * against bounds from two real scores: a greedy descent from the level above's winner, tree_greedy_seed_kernel) has
+ * GHOST children -- they get their place in the level (count, hence offsets and ordinals) and nothing else.  A tile all
+ * of whose parents are such is flagged; the expansion writes 8 bytes per child of it instead of simulating and storing
+ * 84.  Exactness: the seeds are scores of leaves that exist, so each level's minimum is at most its seed, and a ghost
+ * (or a ghost's child) scores above the near-tie window of the seed. */
+template <bool FAST>
+__global__ __launch_bounds__(64) void tree_greedy_seed_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t lead, int level,
+                                                              double refine_rel, double *__restrict__ seed)
+{
+    __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
+    __shared__ double rec[12];                                        /* the best child as a one-node level */
+    __shared__ float rec_margin;
+    const DevProblem &P = probs[0];
+    double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
+    stage_problem(P, cpL, subL);
+    LevelPtrs S{rec + 0, rec + 1, rec + 2, rec + 3, rec + 4, rec + 5, rec + 6, rec + 7, rec + 8, rec + 9, rec + 10,
+                nullptr, nullptr, nullptr, &rec_margin};
+    const uint32_t j = threadIdx.x;
+    const uint32_t n1 = A.offset[lead + 1] - A.offset[lead];
+    uint64_t k1 = ~0ull, o1 = j;
+    if (FAST) {
+        FastChild ch;
+        if (j < n1) { ch = make_child_fast(P, cpL, subL, A, lead, j, level); k1 = key_of(ch.score); }
+        uint64_t k = k1, o = o1;
+        wave_argmin(k, o);
+        k = __shfl(k, 0, 64); o = __shfl(o, 0, 64);
+        if (j == o && k < KEY_INF) {
+            rec[0] = ch.s.x; rec[1] = ch.s.y; rec[2] = ch.s.sh; rec[3] = ch.s.v; rec[4] = ch.s.rpm; rec[5] = ch.s.ch; rec[6] = 0;
+            rec[7] = ch.r; rec[8] = ch.t; rec[9] = 0; rec[10] = 0; rec_margin = 0.0f;
+        }
+        k1 = k;
+    } else {
+        Child ch;
+        if (j < n1) { ch = make_child(P, cpL, subL, A, lead, j, level); k1 = key_of(ch.score); }
+        uint64_t k = k1, o = o1;
+        wave_argmin(k, o);
+        k = __shfl(k, 0, 64); o = __shfl(o, 0, 64);
+        if (j == o && k < KEY_INF) {
+            rec[0] = ch.s.x; rec[1] = ch.s.y; rec[2] = ch.s.h; rec[3] = ch.s.v; rec[4] = ch.s.rpm; rec[5] = ch.s.cmg; rec[6] = ch.s.sog;
+            rec[7] = ch.r; rec[8] = ch.t; rec[9] = ch.cum; rec[10] = ch.score; rec_margin = 0.0f;
+        }
+        k1 = k;
+    }
+    __syncthreads();
+    uint64_t k2 = ~0ull, o2 = j;
+    if (k1 < KEY_INF) {                                               /* uniform */
+        const uint32_t n2 = control_count(P, rec[7], rec[8]);
+        if (j < n2) k2 = key_of(FAST ? make_child_fast(P, cpL, subL, S, 0, j, level + 1).score : make_child(P, cpL, subL, S, 0, j, level + 1).score);
+        wave_argmin(k2, o2);
+    }
+    if (threadIdx.x == 0) {
+        const double rel = FAST ? 2.0 * refine_rel : 1.0e-9;          /* the windows of tree_bound_update */
+        const uint64_t ks[2] = {k1, k2};
+        for (int q = 0; q < 2; q++) {
+            double dmax = __longlong_as_double(-1ll);                 /* NaN: no bound */
+            if (ks[q] < KEY_INF) {
+                const double d = log(mpc_refine_limit(__longlong_as_double((long long)ks[q]), rel, P.wd, P.wh, P.ws) / P.wd);
+                if (d >= 0.0) dmax = d;
+            }
+            seed[q] = dmax;
+        }
+    }
+}
+
+/* 256 tiles of the level to be expanded per workgroup, as tile_select_kernel: flags[t] = 1 when every parent of the tile's
+ * children has only ghosts for children (see above); counts the tiles that are not */
+template <bool FAST>
+__global__ __launch_bounds__(256) void ghost_select_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
+                                                           const uint32_t *__restrict__ bpar, uint32_t n_tiles, int level,
+                                                           const double *__restrict__ seed, uint32_t *__restrict__ flags,
+                                                           uint32_t *__restrict__ real_tiles)
+{
+    __shared__ uint32_t s_f[256];
+    const DevProblem &P = probs[0];
+    const uint32_t t0 = blockIdx.x * 256, nt = min(256u, n_tiles - t0);
+    s_f[threadIdx.x] = 1u;
+    __syncthreads();
+    const double dm1 = seed[0], dm2 = seed[1];
+    const double *c2 = P.cp + (level + 1) * CP_STRIDE;               /* the grandchildren's checkpoint */
+    const uint32_t p_lo = bpar[t0], p_hi = t0 + nt < n_tiles ? min(bpar[t0 + nt] + 1, n_parent) : n_parent;
+    for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += 256) {
+        const uint32_t a = A.offset[p], b = A.offset[p + 1];
+        if (b <= a) continue;
+        bool ghosts = margin_beyond(A.margin[p], dm1);
+        if (ghosts) {
+            float m2;
+            if (FAST) m2 = node_margin<2>(P, c2[6], c2[7], A.x[p], A.y[p], A.v[p], A.rpm[p], A.h[p], A.cmg[p]);
+            else {
+                double sh, ch;
+                sincos(A.h[p], &sh, &ch);
+                m2 = node_margin<2>(P, c2[0] - 2.0 * P.reach_cx, c2[1] - 2.0 * P.reach_cy, A.x[p], A.y[p], A.v[p], A.rpm[p], sh, ch);
+            }
+            ghosts = margin_beyond(m2, dm2) && m2 != MARGIN_GHOST;
+        }
+        if (!ghosts) {
+            const uint32_t ta = max(a >> 8, t0), tb = min((b - 1) >> 8, t0 + nt - 1);
+            for (uint32_t t = ta; t <= tb; t++) s_f[t - t0] = 0u;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nt) {
+        flags[t0 + threadIdx.x] = s_f[threadIdx.x];
+        if (!s_f[threadIdx.x]) atomicAdd(real_tiles, 1u);
+    }
+}
+
 #define TILE_LIST_MIN 8192u      /* tiles (2.1e6 leaves) from which a final level is worth the list's two launches and one read-back */
 
 /* ---- host ------------------------------------------------------------------------------------------------------ */
@@ -1034,6 +1182,7 @@ void mpc_tree_free(mpc_hip_handle *h)
     (void)hipFree(h->d_level_ptrs); h->d_level_ptrs = nullptr;
     (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
     (void)hipFree(h->d_tile_list); h->d_tile_list = nullptr; h->cap_tile_list = 0;
+    (void)hipFree(h->d_tree_seed); h->d_tree_seed = nullptr;
     (void)hipFree(h->d_tree_meta); h->d_tree_meta = nullptr;
     (void)hipHostFree(h->h_tree_meta); h->h_tree_meta = nullptr;
 }
@@ -1264,11 +1413,11 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         if (int s = publish_level(h, it + 1)) return s;
         uint32_t n_tiles = (nchild + 255) / 256;
         if (int s = mpc_ensure_partials(h, (n_tiles + EXPAND_TILES - 1) / EXPAND_TILES + 4096)) return s;
+        /* diagnostic, with MPC_HIP_TREE_SYNC_LEVELS: the list (and the ghosts) from this many tiles on (1: for every final level
+         * -- how the random runs of tools/fuzz_tree.py reach these paths with their shallow trees) */
+        static const uint32_t list_min = getenv("MPC_HIP_TREE_LIST_MIN") ? (uint32_t)strtoul(getenv("MPC_HIP_TREE_LIST_MIN"), nullptr, 10) : TILE_LIST_MIN;
         /* a wide final level: the short list of its tiles (seed_tiles_kernel / tile_select_kernel above) */
         const uint32_t *d_list = nullptr;
-        /* diagnostic, with MPC_HIP_TREE_SYNC_LEVELS: the list from this many tiles on (1: for every final level -- how the
-         * random runs of tools/fuzz_tree.py reach this path with their shallow trees) */
-        static const uint32_t list_min = getenv("MPC_HIP_TREE_LIST_MIN") ? (uint32_t)strtoul(getenv("MPC_HIP_TREE_LIST_MIN"), nullptr, 10) : TILE_LIST_MIN;
         if (!stored && n_tiles >= list_min) {
             if ((size_t)n_tiles + 4 > h->cap_tile_list) {
                 HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1296,6 +1445,32 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             memcpy(&listed, h->h_pair, sizeof listed);
             if (listed > 0 && listed <= n_tiles) { d_list = h->d_tile_list + 4; n_tiles = listed; }      /* (0: cannot happen -- the seed's own tile is listed) */
         }
+        /* the level above a final level (the last one asked for comes next): its tiles of ghosts (ghost_select_kernel) */
+        const uint32_t *d_ghost = nullptr;
+        static const bool ghosts_on = !(getenv("MPC_HIP_TREE_GHOSTS") && atoi(getenv("MPC_HIP_TREE_GHOSTS")) == 0);   /* diagnostic: 0 = none */
+        if (stored && ghosts_on && it + 2 == max_levels && completed == it && it >= 1 && n_tiles >= list_min) {
+            if ((size_t)n_tiles + 4 > h->cap_tile_list) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                (void)hipFree(h->d_tile_list); h->d_tile_list = nullptr; h->cap_tile_list = 0;
+                HIP_TRY(hipMalloc(&h->d_tile_list, sizeof(uint32_t) * ((size_t)n_tiles + 4)));
+                h->cap_tile_list = (size_t)n_tiles + 4;
+            }
+            if (!h->d_tree_seed) HIP_TRY(hipMalloc(&h->d_tree_seed, sizeof(double) * 2));
+            const uint64_t lead = best_leaf >= A.first && best_leaf - A.first < n ? best_leaf - A.first : n / 2;
+            HIP_TRY(hipMemsetAsync(h->d_tile_list, 0, sizeof(uint32_t), h->stream));
+            if (fast) {
+                hipLaunchKernelGGL(tree_greedy_seed_kernel<true>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)lead, it,
+                                   (double)MPC_REFINE_REL, h->d_tree_seed);
+                hipLaunchKernelGGL(ghost_select_kernel<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
+                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_list + 4, h->d_tile_list);
+            } else {
+                hipLaunchKernelGGL(tree_greedy_seed_kernel<false>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)lead, it,
+                                   0.0, h->d_tree_seed);
+                hipLaunchKernelGGL(ghost_select_kernel<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
+                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_list + 4, h->d_tile_list);
+            }
+            d_ghost = h->d_tile_list + 4;
+        }
         const uint32_t tpb = std::min<uint32_t>(EXPAND_TILES, std::max<uint32_t>(1, n_tiles / 4096));   /* >= 4096 workgroups first */
         const uint32_t nblk = (n_tiles + tpb - 1) / tpb;
         if (int s = mpc_ensure_partials(h, nblk)) return s;
@@ -1303,7 +1478,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             if (stored)
                 hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
                                    nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
-                                   (const uint32_t *)nullptr, 0u);
+                                   d_ghost, 0u);
             else
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
                                    nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
@@ -1313,7 +1488,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, (const uint32_t *)nullptr, 0u);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, d_ghost, 0u);
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
                                    tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, d_list, n_tiles);

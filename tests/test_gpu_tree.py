@@ -4,6 +4,8 @@ the returned trajectory / first control.  Scenarios follow the reference's test_
 semicircle of updateReferenceTrajectoryTest (:449-467) and the go-straight / turn scenarios of the
 commented-out tests (:44-267)."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -374,6 +376,23 @@ def test_deepening_beyond_one_expansion_equals_the_shards(solver, prec):
     cut, cl = solver.solve_tree_deep(p, depth, precision=prec, now=clock, end_time=40.0)
     assert cut.status == 0 and cut.levels == 7, (cut.levels, t[0])
     assert traj_array(cut).tobytes() == traj_array(plain).tobytes() and cut.best_ordinal == plain.best_ordinal
+
+
+def test_ghosts_and_short_list_change_no_result():
+    """the level above a final level keeps only a place (no state) for nodes that cannot matter (mpc_tree.hip: ghosts) and the
+    final level is expanded from a short list of its tiles: two child processes search the depth-8 tree (5.2e9 leaves, in
+    pieces), one with the library's diagnostic switch that turns the ghosts off -- same levels, leaves, first control,
+    ordinal and tie flag"""
+    import subprocess
+    probe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_probe_deep.py")
+    lines = []
+    for ghosts in ("1", "0"):
+        r = subprocess.run([sys.executable, "-u", probe, "fast", "8", "1"], env=dict(os.environ, MPC_HIP_TREE_GHOSTS=ghosts),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=200)
+        assert r.returncode == 0, r.stdout[-2000:]
+        line = [l for l in r.stdout.splitlines() if " deep depth=8 " in l][-1]
+        lines.append(" ".join(w for w in line.split() if not w.startswith("wall_ms=")))
+    assert lines[0] == lines[1] and "levels=8 leaves=5172889071" in lines[0], lines
 
 
 def _leaf_controls(p, depth):
