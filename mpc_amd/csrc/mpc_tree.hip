@@ -1626,10 +1626,13 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
     while (L < max_levels && h->tree_stopped_by_width) {
         if (now && now(now_ctx) >= end_time) break;
         const int target = L + 1;
-        /* pieces: contiguous slices of a shallow level's nodes, so many that a piece's leaves fit 32-bit ordinals (<= 30
-         * children per node, a quarter of slack for uneven subtrees) and its slice of level L fits the storage cap */
+        /* pieces: contiguous slices of a shallow level's nodes, so many that a piece's leaves fit 32-bit ordinals and its
+         * slice of level L fits the storage cap */
+        /* (the next level's size: the last level's growth, at most 30-fold, and half as much again for uneven subtrees; a
+         * piece that does not fit after all shows at its own scan, and the level is started over with twice the pieces) */
         const double leaves_L = (double)lv[(size_t)L - 1].n_leaves;
-        uint32_t pieces = (uint32_t)std::max(2.0, ceil(std::max(leaves_L * 30.0 * 1.25 / 4.0e9, leaves_L * 1.25 / (double)(1u << 28))));
+        const double growth = L >= 2 ? std::min(30.0, leaves_L / (double)std::max<uint64_t>(lv[(size_t)L - 2].n_leaves, 1)) : 30.0;
+        uint32_t pieces = (uint32_t)std::max(2.0, ceil(std::max(leaves_L * growth * 1.5 / 4.0e9, leaves_L * 1.5 / (double)(1u << 28))));
         bool done = false, abandoned = false;
         for (int attempt = 0; attempt < 3 && !done && !abandoned; attempt++, pieces *= 2) {
             int split = 1;

@@ -368,13 +368,19 @@ def test_deepening_beyond_one_expansion_equals_the_shards(solver, prec):
     assert deep.best_ordinal == ordinal and deep.best_last == dl[7].best_score
     assert traj_array(deep).tobytes() == traj_array(shards[owner][0]).tobytes()
     assert deep.evaluated == sum(dl[l].n_leaves for l in range(8))
-    # the clock: 1 s per poll; the plain search polls a handful of times, the pieces' searches many more
+    # the clock: 1 s per poll.  Counted first (a deadline far away): the plain search polls a handful of times, the pieces'
+    # searches many more; then a deadline half way between the two runs out among the pieces
     t = [0.0]
     def clock():
         t[0] += 1.0
         return t[0]
-    cut, cl = solver.solve_tree_deep(p, depth, precision=prec, now=clock, end_time=40.0)
-    assert cut.status == 0 and cut.levels == 7, (cut.levels, t[0])
+    solver.solve_tree(p, depth, precision=prec, now=clock, end_time=1e9)
+    polls_plain, t[0] = t[0], 0.0
+    full, _ = solver.solve_tree_deep(p, depth, precision=prec, now=clock, end_time=1e9)
+    polls_deep, t[0] = t[0], 0.0
+    assert full.levels == 8 and polls_deep >= polls_plain + 4
+    cut, cl = solver.solve_tree_deep(p, depth, precision=prec, now=clock, end_time=0.5 * (polls_plain + polls_deep))
+    assert cut.status == 0 and cut.levels == 7, (cut.levels, t[0], polls_plain, polls_deep)
     assert traj_array(cut).tobytes() == traj_array(plain).tobytes() and cut.best_ordinal == plain.best_ordinal
 
 
