@@ -385,12 +385,14 @@ int         mpc_hip_timing(mpc_hip_handle *h, int reset, uint64_t *runs, double 
  * precision: MPC_PREC_F64 expands with the reference's arithmetic.  MPC_PREC_FAST expands with the streamlined model
  * and lets the reference's arithmetic decide: every leaf within MPC_REFINE_REL of a level's minimum is re-evaluated
  * along its path from the root with the strict model, and the returned scores and trajectory are the strict
- * path's -- the same leaf and the same bits as MPC_PREC_F64, ~1.7x sooner at depth 7.
+ * path's -- the same leaf and the same bits as MPC_PREC_F64, ~1.4x sooner at depth 7.
  * The LAST level expanded is searched, not enumerated (both precisions): all three terms of compareStates are >= 0, so
  * a leaf farther from its checkpoint than log(best score so far / w_distance) cannot win, and a node that cannot bring
  * any child that near within one level -- a bound on how far and in which directions the hull can travel in a level,
  * derived from the model's own recurrence (VehicleState.h:111-148) and the hull's parameters -- is not simulated at all
- * (97 % of the depth-7 level of the reference's semicircle scenario).  What is returned is what the full enumeration
+ * (97 % of the depth-7 level of the reference's semicircle scenario), and when max_levels makes a level the last one with
+ * children, those of its nodes that can matter neither to its own record nor to the final level's get only their place in
+ * it (their child count) -- two-level reach against two scores found by a greedy descent.  What is returned is what the full enumeration
  * returns: the level's first strict minimum in DFS order, its ordinal, scores, trajectory and libm_tie flag;
  * mpc_result.evaluated / rollout_steps and mpc_tree_level.n_leaves count the tree's nodes as the reference walks them,
  * whether or not this library had to simulate them. */
@@ -421,7 +423,7 @@ int         mpc_hip_solve_tree_shard(mpc_hip_handle *h, const mpc_problem *h_pro
  * in ~2 ms of the 100 ms the planner grants.  This entry point goes on from there: each further level is searched in
  * pieces -- the shards above, one after the other on this handle, as many as make a piece's leaves fit -- and the pieces'
  * winners are combined as the shards' are: the smallest (strict score, global DFS ordinal).  Depth 8 (5.2e9 leaves) takes
- * ~23 ms (MPC_PREC_FAST) on one MI355X.  A level counts only if all its pieces finished before end_time
+ * 12-15 ms (MPC_PREC_FAST) on one MI355X, depth 9 (8.8e10) 173 ms.  A level counts only if all its pieces finished before end_time
  * (controller.cpp:101-103: an unfinished iteration is discarded); h_level_best / h_result then stay the previous
  * level's.  now == NULL runs to max_levels whatever that takes.  Results are those of one search of the same depth: same
  * leaf, same scores, same trajectory; best_ordinal and h_level_best[].best_leaf are 64-bit DFS ordinals of the whole level.

@@ -69,14 +69,17 @@ if which == "tree":
     print("# + one compareStates: 11 x 54 + 21 = 615 FLOP.  Counters: mean over the probe's launches with the kernel's largest grid.")
     print("# SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles.")
     print("#")
-    print("# <true> kernels = a STORED level: every child simulated and written (level 6: 17,827,584 nodes) -- the kernels' plain rate.")
+    print("# <true> kernels = the largest STORED level, level 6 (17,827,584 nodes).  In a depth-7 search it is the level above the final")
+    print("# one: only tiles that can matter to its own record or to the final level are simulated and stored, the others get 8 bytes")
+    print("# per node (ghosts, ghost_select_kernel).  Simulated in full (MPC_HIP_TREE_GHOSTS=0) the same launch took 580 us (fast: 866")
+    print("# VALU instructions per node, 69 % VALU-busy, 1.45 GB of stores) / 1497 us (strict: 2298 per node, 76 %, 1.87 GB).")
     print("# <false> kernels = the FINAL level (303,370,833 leaves), which is searched, not enumerated: the launch runs over the short")
-    print("# list of tiles within reach of the checkpoint (tile_select_kernel) and skips waves that cannot win; its 'algorithmic'")
-    print("# lines below price the reference's full enumeration of that level against the time this launch took -- an equivalent")
-    print("# rate, not arithmetic the GPU performed (the hardware-counted line is what it performed).")
+    print("# list of tiles within reach of the checkpoint (tile_select_kernel) and skips waves that cannot win.")
+    print("# For both, the 'algorithmic' lines price the reference's full enumeration of the level against the time the launch took --")
+    print("# an equivalent rate, not arithmetic the GPU performed (the hardware-counted line is what it performed).")
     print()
-    report("expand_fast_kernel<true> (MPC_PREC_FAST, stored level 6)", src + "/tree_fast", "expand_fast_kernel<true>", 17827584, "node", 615, True)
-    report("expand_kernel<true> (MPC_PREC_F64, stored level 6)", src + "/tree_strict", "expand_kernel<true>", 17827584, "node", 615, True)
+    report("expand_fast_kernel<true> (MPC_PREC_FAST, stored level 6, with ghosts)", src + "/tree_fast", "expand_fast_kernel<true>", 17827584, "node", 615, True)
+    report("expand_kernel<true> (MPC_PREC_F64, stored level 6, with ghosts)", src + "/tree_strict", "expand_kernel<true>", 17827584, "node", 615, True)
     report("expand_fast_kernel<false> (MPC_PREC_FAST, final level 7, short list)", src + "/tree_fast", "expand_fast_kernel<false>",
            303370833, "leaf", 615, True)
     report("expand_kernel<false> (MPC_PREC_F64, final level 7, short list)", src + "/tree_strict", "expand_kernel<false>",
