@@ -334,26 +334,39 @@ def combine_tree_levels(gathered, split_level):
     return out
 
 
-def solve_tree_sharded(solver, problem, max_levels, split_level, precision=1, group=None):
+def solve_tree_sharded(solver, problem, max_levels, split_level, precision=1, group=None, pieces_per_rank=1):
     """Every rank of `group` runs its shard of the search on its GPU, the per-level records are all-gathered (24 bytes
-    per level and rank) and combined.  -> (combined levels, this rank's Result, owner rank of the final winner)."""
+    per level, piece and rank) and combined.  -> (combined levels, this rank's Result, owner rank of the final winner).
+    pieces_per_rank > 1: the search is cut into world x pieces_per_rank shards and a rank runs its consecutive
+    pieces_per_rank of them one after the other (a level too wide for one expansion's 32-bit ordinals even as a
+    world-th: depth 9 of the reference's control sets -- 8.8e10 leaves -- on 8 GPUs x 5 pieces); the Result returned is
+    that of the rank's best piece."""
     on = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if on else 1
     rank = dist.get_rank(group) if on else 0
-    res, levels = solver.solve_tree(problem, max_levels, precision, split_level=split_level, shard=rank, n_shards=world)
+    ppr = int(pieces_per_rank)
+    assert ppr >= 1
+    runs = [solver.solve_tree(problem, max_levels, precision, split_level=split_level, shard=rank * ppr + k, n_shards=world * ppr)
+            for k in range(ppr)]
     dev = "cuda" if on and dist.get_backend(group) == "nccl" else "cpu"
-    n_levels = int(res.levels)
+    n_levels = min(int(r.levels) for r, _ in runs)
     if world > 1:
         # shards expand slices of different widths: a node budget, the storage cap or memory can stop them at different
         # depths.  Only the levels EVERY shard completed can be combined (and the gather needs equal shapes).
         common = torch.tensor([n_levels], dtype=torch.int64, device=dev)
         dist.all_reduce(common, op=dist.ReduceOp.MIN, group=group)
         n_levels = int(common.item())
-    mine = tree_levels_tensor(levels, n_levels, dev).view(n_levels, 3)
+    mine = torch.stack([tree_levels_tensor(lv, n_levels, dev).view(n_levels, 3) for _, lv in runs])      # [ppr, n_levels, 3]
     if world > 1:
         gathered = torch.empty((world,) + tuple(mine.shape), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+        dist.all_gather_into_tensor(gathered.view(-1), mine.contiguous().view(-1), group=group)
+        gathered = gathered.view(world * ppr, n_levels, 3)                                                 # shard order = slice order
     else:
-        gathered = mine.unsqueeze(0)
+        gathered = mine
     combined = combine_tree_levels(gathered, split_level)
-    return combined, res, combined[-1][3]
+    owner_shard = combined[-1][3]
+    # this rank's own best piece (by the last common level's score, then ordinal: pieces are in DFS order)
+    last = n_levels - 1
+    best = min(range(ppr), key=lambda k: (int(mine[k, last, 1]) if int(mine[k, last, 2]) != -1 else 2 ** 63 - 1, k))
+    res = runs[owner_shard - rank * ppr][0] if rank * ppr <= owner_shard < (rank + 1) * ppr else runs[best][0]
+    return combined, res, owner_shard // ppr

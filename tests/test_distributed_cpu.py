@@ -150,6 +150,45 @@ def test_sharded_tree_levels_combine_over_gloo():
     assert combined[3] == (54000, 17, _bits(0.125), 0) and owner == 0
 
 
+def _pieces_worker(rank, world, port, table, out):
+    from mpc_amd.distributed import solve_tree_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    solver = _FakeSolver(table)
+    asked = []
+    plain = solver.solve_tree
+    def spy(problem, max_levels, precision, split_level, shard, n_shards):
+        asked.append((shard, n_shards))
+        return plain(problem, max_levels, precision, split_level, shard, n_shards)
+    solver.solve_tree = spy
+    combined, res, owner = solve_tree_sharded(solver, None, 4, split_level=2, pieces_per_rank=2)
+    out[rank] = (combined, owner, asked)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_tree_with_several_pieces_per_rank():
+    """a level too wide even for a world-th of it (depth 9 on a node): world x pieces shards, a rank runs its consecutive
+    pieces one after the other; the combination is that of the 4 shards in slice order, the owner the rank that ran the piece"""
+    from mpc_amd.distributed import combine_tree_levels, tree_levels_tensor
+    table = [
+        [(15, 4, 2.5), (270, 33, 1.5), (1000, 999, 0.75), (18000, 17, 0.25)],
+        [(15, 4, 2.5), (270, 33, 1.5), (1200, 5, 0.5), (20000, 0, 0.25)],
+        [(15, 4, 2.5), (270, 33, 1.5), (900, 0, 0.75), (16000, 3, 0.125)],
+        [(15, 4, 2.5), (270, 33, 1.5), (800, 7, 0.5), (15000, 9, 0.125)],
+    ]
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_pieces_worker, args=(2, _free_port(), table, out), nprocs=2, join=True)
+        res = [out[r] for r in range(2)]
+    assert res[0][:2] == res[1][:2]
+    assert res[0][2] == [(0, 4), (1, 4)] and res[1][2] == [(2, 4), (3, 4)]
+    combined, owner, _ = res[0]
+    want = combine_tree_levels(torch.stack([tree_levels_tensor([_FakeLevel(*t) for t in table[s]], 4) for s in range(4)]), 2)
+    assert combined == want
+    assert combined[2] == (3900, 1000 + 5, _bits(0.5), 1) and combined[3] == (69000, 18000 + 20000 + 3, _bits(0.125), 2) and owner == 1
+
+
 def _exact_worker(rank, world, port, out):
     from mpc_amd.distributed import combine_winners_exact
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)

@@ -74,3 +74,17 @@ def test_cross_rank_near_tie_is_decided_by_the_strict_model(tmp_path):
         assert g0["exact"]["rank"] == rank_a                                    # ... the reference's arithmetic a
         assert g0["exact"]["bits"] == r0["strict_a_bits"]
         assert g0["tied_rows"] == g1["tied_rows"] == i + 1                      # one near-tie row per round, on each rank's handle
+
+
+def test_two_ranks_search_depth_8_together(tmp_path):
+    """the tree search over ranks (distributed.solve_tree_sharded), one shard per rank and two pieces per rank: the combined
+    depth-8 record (5.2e9 leaves) is the one mpc_hip_solve_tree_deep finds on a single handle, on both ranks, and exactly one
+    rank holds the winner's result"""
+    r0, r1 = _run("tree", tmp_path)
+    assert r0["deep"] == r1["deep"] and r0["deep"]["levels"] == 8 and r0["deep"]["leaves"] == 5172889071
+    for key in ("ppr1", "ppr2"):
+        for r in (r0, r1):
+            got = {k: r[key][k] for k in ("levels", "leaves", "ordinal", "bits")}
+            assert got == r0["deep"], (key, r["rank"], got, r0["deep"])
+        assert r0[key]["owner"] == r1[key]["owner"]
+        assert [r0[key]["mine_is_winner"], r1[key]["mine_is_winner"]].count(True) == 1

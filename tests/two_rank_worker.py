@@ -3,7 +3,7 @@ process that has touched the GPU), process group gloo, BOTH ranks on cuda:0 -- R
 gloo does not care -- so that the world-size-2 code of mpc_amd/distributed.py runs end to end with real kernels on
 every rank on a 1-GPU box.  Writes what it saw as JSON; the test compares the ranks and asserts.
 
-    RANK=r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/two_rank_worker.py shards|flip out.json
+    RANK=r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/two_rank_worker.py shards|flip|tree out.json
 """
 import json
 import os
@@ -111,6 +111,23 @@ def run_flip(torch, dist, M, W, solver, rank, world):
     return out
 
 
+def run_tree(torch, dist, M, W, solver, rank, world):
+    """depth 8 (5.2e9 leaves) as solve_tree_sharded runs it: one shard per rank, and again with two pieces per rank; the
+    combined record against mpc_hip_solve_tree_deep on this rank's own handle"""
+    from mpc_amd.distributed import solve_tree_sharded
+    depth = 8
+    p = W.config1_problem(depth=depth)[0]
+    deep, dl = solver.solve_tree_deep(p, depth, precision=M.PREC_FAST)
+    out = {"deep": {"levels": int(deep.levels), "leaves": int(dl[depth - 1].n_leaves), "ordinal": int(dl[depth - 1].best_leaf),
+                    "bits": bits(dl[depth - 1].best_score)}}
+    for ppr in (1, 2):
+        combined, res, owner = solve_tree_sharded(solver, p, depth, split_level=3, precision=M.PREC_FAST, pieces_per_rank=ppr)
+        total, ordinal, kbits, shard = combined[-1]
+        out["ppr%d" % ppr] = {"levels": len(combined), "leaves": int(total), "ordinal": int(ordinal), "bits": int(kbits), "owner": int(owner),
+                              "mine_is_winner": bool(owner == rank and bits(res.best_last) == int(kbits))}
+    return out
+
+
 def main():
     import faulthandler
     faulthandler.enable()                           # a crash in native code names the Python line it came from
@@ -126,7 +143,7 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):                 # the combiner's staging copies run on torch's current stream: the solver's
         solver = M.Solver(0, stream=stream.cuda_stream)
-        out = (run_shards if case == "shards" else run_flip)(torch, dist, M, W, solver, rank, world)
+        out = {"shards": run_shards, "flip": run_flip, "tree": run_tree}[case](torch, dist, M, W, solver, rank, world)
         solver.close()
     out["rank"], out["world"] = rank, dist.get_world_size()
     with open(out_path, "w") as f:
