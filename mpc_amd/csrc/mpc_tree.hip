@@ -10,9 +10,18 @@
  * every deepening iteration's result.  The deadline of :101-103 is polled between levels; a level that does
  * not complete before end_time is discarded exactly as the reference discards an unfinished iteration.
  *
- * Kernels per level:  count_kernel (children per node, control sets of :121-146) -> 3-kernel exclusive scan
- * -> expand_kernel (one lane per child: parent lookup by binary search, strict FP64 simulate + score, SoA store,
- * wavefront/LDS argmin) -> level_reduce_kernel.  After the last level trace_kernel walks the parent links (one tiny launch per level).
+ * Map of this file:
+ *   control_pick / control_count     the control sets of :121-146, per child, in registers
+ *   scan_*_kernel                    exclusive scan of the child counts -> offsets (= DFS ordinals) and bpar[] (a tile's first parent)
+ *   expand_kernel / expand_fast_kernel<STORE>   one lane per child: parent from an LDS window of offsets, simulate + score
+ *                                    (the reference's arithmetic / the streamlined model), SoA store of a stored level, argmin
+ *   tree_finish_body                 fast expansion: the near-tie leaves once more along their paths with the strict model
+ *   tree_post_kernel                 levels 1-4 without host round trips (reduction + the next level's count and scan)
+ *   level_reduce / leaf_record / trace kernels   strict expansion: a level's winner, its record, the winner's trajectory
+ *   node_margin, tile_select_kernel, tree_bound_*   the FINAL level as a search: reach bounds, the short list of tiles, the bound
+ *   tree_greedy_seed_kernel, ghost_select_kernel    the level above it: ghosts
+ *   solve_tree_once                  one search (or one shard of one); mpc_hip_solve_tree_deep: further levels in pieces
+ * DESIGN.md sections 6 and 7 tell the story and the measurements.
  */
 #include <math.h>
 #include <string.h>
