@@ -206,6 +206,7 @@ struct mpc_hip_handle {
     uint32_t *d_bpar = nullptr; size_t cap_bpar = 0;              /* first parent of every 256-child workgroup */
     double *d_tree_seed = nullptr;                                /* tree search: [0..1] seed bounds of the last two levels (ghost_select_kernel) */
     bool tree_stopped_by_width = false;                          /* the last tree search ended because the next level does not fit one expansion */
+    uint32_t *d_tile_flags = nullptr; size_t cap_tile_flags = 0; /* tree search: ghost flag per tile of the level above the final one */
     uint32_t *d_tile_list = nullptr; size_t cap_tile_list = 0;   /* tree search, final level: [0] count, [1..2] seed tiles, [4..] the short list */
     LevelPtrs *d_level_ptrs = nullptr;                           /* [MPC_MAX_DEPTH + 2], fast-mode path walks */
     std::vector<LevelPtrs> h_level_ptrs;                         /* its host image (copies are asynchronous) */

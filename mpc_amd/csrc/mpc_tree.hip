@@ -384,9 +384,9 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
-    /* tile_list, final level (!STORE): its short list (tile_select_kernel) -- the workgroup's tiles are entries of the list;
-     * stored level: one flag per tile, non-zero = a tile of ghosts (ghost_select_kernel) */
-    const uint32_t *list = STORE ? nullptr : tile_list, *ghost = STORE ? tile_list : nullptr;
+    /* tile_list: the workgroup's tiles are entries of the list -- the final level's short list (tile_select_kernel), or the
+     * tiles of the level above it that are not ghosts' (ghost_select_kernel) */
+    const uint32_t *list = tile_list;
     const uint32_t n_tiles = list ? n_list : (n_child + 255) / 256;
     const uint32_t slot0 = blockIdx.x * tpb;
     if (slot0 >= n_tiles) {                                          /* uniform: a workgroup beyond the level */
@@ -394,7 +394,6 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
         return;
     }
     const uint32_t tile0 = list ? list[slot0] : slot0;
-    uint32_t ghost_tile = ghost ? ghost[tile0] : 0u;
     uint32_t par0 = bpar[tile0];                                     /* the parent of the tile's first child (scan_apply_kernel) */
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
@@ -407,11 +406,10 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     uint32_t tile = tile0;
     for (uint32_t i = 0; i < tpb && slot0 + i < n_tiles; i++) {
         const bool more = i + 1 < tpb && slot0 + i + 1 < n_tiles;
-        uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0, ghost_next = 0;
+        uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0;
         if (more) {                                                   /* in flight during this tile's arithmetic */
             tile_next = list ? list[slot0 + i + 1] : tile + 1;
             par_next = bpar[tile_next];
-            ghost_next = ghost ? ghost[tile_next] : 0u;
             p_next = min(par_next + threadIdx.x, n_parent);
             if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
         }
@@ -420,16 +418,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
          * workgroup, so that leaving a tile out is a uniform decision: no parent of the tile has a child within reach */
         const double dmax = STORE ? 0.0 : s_dmax[i & 1];
         const bool skip_tile = !STORE && margin_beyond(s_margin[i & 1], dmax);
-        if (STORE && ghost_tile) {                                    /* uniform: a place in the level, nothing else */
-            if (c < n_child) {
-                uint32_t first;
-                const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
-                double r, t;
-                control_pick(P, A.last_r[par], A.last_t[par], c - first, r, t);
-                B.count[c] = control_count(P, r, t);
-                B.margin[c] = MARGIN_GHOST;
-            }
-        } else if (!skip_tile && c < n_child) {
+        if (!skip_tile && c < n_child) {
             uint32_t first;
             const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
             const Child ch = make_child<!STORE>(P, cpL, subL, A, par, c - first, level, dmax);
@@ -449,7 +438,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
                 if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
             }
             if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
-            par0 = par_next; tile = tile_next; ghost_tile = ghost_next;
+            par0 = par_next; tile = tile_next;
             __syncthreads();
         }
     }
@@ -601,9 +590,9 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     const DevProblem &P = probs[0];
     double *cpL = lds, *subL = lds + MPC_MAX_DEPTH * CP_STRIDE;
     if (meta_parent) { n_parent = (uint32_t)meta_parent[0]; n_child = (uint32_t)meta_parent[TREE_META]; }
-    /* tile_list, final level (!STORE): its short list (tile_select_kernel) -- the workgroup's tiles are entries of the list;
-     * stored level: one flag per tile, non-zero = a tile of ghosts (ghost_select_kernel) */
-    const uint32_t *list = STORE ? nullptr : tile_list, *ghost = STORE ? tile_list : nullptr;
+    /* tile_list: the workgroup's tiles are entries of the list -- the final level's short list (tile_select_kernel), or the
+     * tiles of the level above it that are not ghosts' (ghost_select_kernel) */
+    const uint32_t *list = tile_list;
     const uint32_t n_tiles = list ? n_list : (n_child + 255) / 256;
     const uint32_t slot0 = blockIdx.x * tpb;
     if (slot0 >= n_tiles) {
@@ -611,7 +600,6 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
         return;
     }
     const uint32_t tile0 = list ? list[slot0] : slot0;
-    uint32_t ghost_tile = ghost ? ghost[tile0] : 0u;
     uint32_t par0 = bpar[tile0];
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
@@ -628,11 +616,10 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
         keys[i] = __longlong_as_double((long long)KEY_INF);
         if (i < tpb && slot0 + i < n_tiles) {                          /* uniform */
             const bool more = i + 1 < tpb && slot0 + i + 1 < n_tiles;
-            uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0, ghost_next = 0;
+            uint32_t tile_next = 0, par_next = 0, p_next = 0, off_next = 0;
             if (more) {
                 tile_next = list ? list[slot0 + i + 1] : tile + 1;
                 par_next = bpar[tile_next];
-                ghost_next = ghost ? ghost[tile_next] : 0u;
                 p_next = min(par_next + threadIdx.x, n_parent);
                 if (threadIdx.x < PARENT_WINDOW) off_next = A.offset[p_next];
             }
@@ -641,16 +628,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
              * workgroup, so that leaving a tile out is a uniform decision: no parent of the tile has a child within reach */
             const double dmax = STORE ? 0.0 : s_dmax[i & 1];
             const bool skip_tile = !STORE && margin_beyond(s_margin[i & 1], dmax);
-            if (STORE && ghost_tile) {                                 /* uniform: a place in the level, nothing else */
-                if (c < n_child) {
-                    uint32_t first;
-                    const uint32_t par = window_parent(win[i & 1], par0, n_parent, c, first);
-                    double r, t;
-                    control_pick(P, A.last_r[par], A.last_t[par], c - first, r, t);
-                    B.count[c] = control_count(P, r, t);
-                    B.margin[c] = MARGIN_GHOST;
-                }
-            } else if (!skip_tile) {
+            if (!skip_tile) {
                 const uint64_t seen = STORE ? 0 : tree_bound_key(bound);
                 uint64_t kc = ~0ull;
                 if (c < n_child) {
@@ -678,7 +656,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
                     if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
                 }
                 if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
-                par0 = par_next; tile = tile_next; ghost_tile = ghost_next;
+                par0 = par_next; tile = tile_next;
                 __syncthreads();
             }
         }
@@ -1042,14 +1020,17 @@ __global__ void seed_tiles_kernel(LevelPtrs A, uint32_t node, uint32_t *__restri
  * its children fall into, then a lane per tile decides */
 __global__ __launch_bounds__(256) void tile_select_kernel(LevelPtrs A, uint32_t n_parent, const uint32_t *__restrict__ bpar,
                                                           uint32_t n_tiles, const uint64_t *bound, uint32_t *__restrict__ list,
-                                                          uint32_t *__restrict__ count)
+                                                          uint32_t *__restrict__ count, const uint32_t *__restrict__ parent_flags)
 {
+    /* parent_flags (optional): the ghost flags of the PARENTS' tiles (ghost_select_kernel, when the parents' level was
+     * expanded with ghosts): a ghost lowers no tile's margin, so its offsets and margin are not even read */
     __shared__ uint32_t s_m[256];                                    /* bits of non-negative floats order like the floats */
     const uint32_t t0 = blockIdx.x * 256, nt = min(256u, n_tiles - t0);
     s_m[threadIdx.x] = 0x7F800000u;
     __syncthreads();
     const uint32_t p_lo = bpar[t0], p_hi = t0 + nt < n_tiles ? min(bpar[t0 + nt] + 1, n_parent) : n_parent;
     for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += 256) {
+        if (parent_flags && parent_flags[p >> 8]) continue;
         const uint32_t a = A.offset[p], b = A.offset[p + 1];
         if (b <= a) continue;
         const uint32_t bits = __float_as_uint(fmaxf(A.margin[p], 0.0f));
@@ -1067,8 +1048,8 @@ __global__ __launch_bounds__(256) void tile_select_kernel(LevelPtrs A, uint32_t 
  * level's checkpoint AND whose grandchildren all end out of reach of the next one (node_margin over one and two levels,
  * against bounds from two real scores: a greedy descent from the level above's winner, tree_greedy_seed_kernel) has
  * GHOST children -- they get their place in the level (count, hence offsets and ordinals) and nothing else.  A tile all
- * of whose parents are such is flagged; the expansion writes 8 bytes per child of it instead of simulating and storing
- * 84.  Exactness: the seeds are scores of leaves that exist, so each level's minimum is at most its seed, and a ghost
+ * of whose parents are such is flagged: ghost_fill_kernel writes 8 bytes per child of it, and the expansion -- simulation and
+ * 84 bytes per child -- runs over the list of the other tiles.  Exactness: the seeds are scores of leaves that exist, so each level's minimum is at most its seed, and a ghost
  * (or a ghost's child) scores above the near-tie window of the seed. */
 template <bool FAST>
 __global__ __launch_bounds__(64) void tree_greedy_seed_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t lead, int level,
@@ -1130,12 +1111,12 @@ __global__ __launch_bounds__(64) void tree_greedy_seed_kernel(const DevProblem *
 }
 
 /* 256 tiles of the level to be expanded per workgroup, as tile_select_kernel: flags[t] = 1 when every parent of the tile's
- * children has only ghosts for children (see above); counts the tiles that are not */
+ * children has only ghosts for children (see above); lists the tiles that are not */
 template <bool FAST>
 __global__ __launch_bounds__(256) void ghost_select_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                            const uint32_t *__restrict__ bpar, uint32_t n_tiles, int level,
                                                            const double *__restrict__ seed, uint32_t *__restrict__ flags,
-                                                           uint32_t *__restrict__ real_tiles)
+                                                           uint32_t *__restrict__ real_list, uint32_t *__restrict__ real_tiles)
 {
     __shared__ uint32_t s_f[256];
     const DevProblem &P = probs[0];
@@ -1167,7 +1148,80 @@ __global__ __launch_bounds__(256) void ghost_select_kernel(const DevProblem *__r
     __syncthreads();
     if (threadIdx.x < nt) {
         flags[t0 + threadIdx.x] = s_f[threadIdx.x];
-        if (!s_f[threadIdx.x]) atomicAdd(real_tiles, 1u);
+        if (!s_f[threadIdx.x]) real_list[atomicAdd(real_tiles, 1u)] = t0 + threadIdx.x;   /* the expansion's list, in any order */
+    }
+}
+
+/* the ghosts' place in the level: the child count (its control set's size) and the margin that says "ghost", for the
+ * children that lie in flagged tiles.  A lane per PARENT: a control set's size is (rudders) x (throttles), each a function
+ * of one last control only, and a parent's children carry at most six different rudders and five throttles -- eleven
+ * small evaluations per parent instead of a parent search, a control_pick and a control_count per child */
+__device__ inline uint32_t rudder_count(const DevProblem &P, double last_r)
+{
+    const double tol = P.tol, low_r = last_r - P.gr, high_r = last_r + P.gr;
+    return 3u + (P.minr + tol < low_r && fabs(P.midr - low_r) > tol) + (fabs(P.midr - high_r) > tol && P.maxr > high_r + tol) +
+           (fabs(P.minr - last_r) > tol && fabs(P.midr - last_r) > tol && fabs(P.maxr - last_r) > tol);
+}
+
+__device__ inline uint32_t throttle_count(const DevProblem &P, double last_t)
+{
+    const double tol = P.tol, low_t = last_t - P.gt, high_t = last_t + P.gt;
+    return 2u + (P.mint + tol < low_t) + (P.maxt > high_t + tol) + (fabs(P.mint - last_t) > tol && fabs(P.maxt - last_t) > tol);
+}
+
+__global__ __launch_bounds__(256) void ghost_fill_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
+                                                         LevelPtrs B, const uint32_t *__restrict__ flags)
+{
+    /* 256 consecutive parents per workgroup: their children are one run of the level; the counts go through LDS so that
+     * the level is written in order, a lane per child (a lane per parent writing its own children scatters 4-byte stores) */
+    __shared__ uint8_t s_cnt[256 * 30];
+    __shared__ uint32_t s_run[2];
+    const uint32_t p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
+    if (threadIdx.x == 0) { s_run[0] = A.offset[p0]; s_run[1] = A.offset[min(p0 + 256u, n_parent)]; }
+    __syncthreads();
+    const uint32_t base = s_run[0], end = s_run[1];
+    bool any = false;
+    for (uint32_t t = (base >> 8) + threadIdx.x; t <= ((max(end, base + 1) - 1) >> 8); t += 256) any |= flags[t] != 0;
+    if (!__syncthreads_or(any)) return;                               /* no ghost among these parents' children */
+    if (p < n_parent) {
+        const uint32_t a = A.offset[p], b = A.offset[p + 1];
+        const DevProblem &P = probs[0];
+        const double last_r = A.last_r[p], last_t = A.last_t[p], tol = P.tol;
+        /* the children's rudders and throttles in the order of control_pick, and the size of each one's own set */
+        const double low_r = last_r - P.gr, high_r = last_r + P.gr, low_t = last_t - P.gt, high_t = last_t + P.gt;
+        const bool r3 = P.minr + tol < low_r && fabs(P.midr - low_r) > tol;
+        const bool r4 = fabs(P.midr - high_r) > tol && P.maxr > high_r + tol;
+        const bool r5 = fabs(P.minr - last_r) > tol && fabs(P.midr - last_r) > tol && fabs(P.maxr - last_r) > tol;
+        const bool t2 = P.mint + tol < low_t, t3 = P.maxt > high_t + tol;
+        const bool t4 = fabs(P.mint - last_t) > tol && fabs(P.maxt - last_t) > tol;
+        uint32_t cr[6], ct[5], nr = 3, nt = 2;
+        cr[0] = rudder_count(P, P.minr); cr[1] = rudder_count(P, P.midr); cr[2] = rudder_count(P, P.maxr);
+        cr[3] = cr[4] = cr[5] = 0;
+        ct[0] = throttle_count(P, P.mint); ct[1] = throttle_count(P, P.maxt);
+        ct[2] = ct[3] = ct[4] = 0;
+        const uint32_t c_low_r = rudder_count(P, low_r), c_high_r = rudder_count(P, high_r), c_last_r = rudder_count(P, last_r);
+        const uint32_t c_low_t = throttle_count(P, low_t), c_high_t = throttle_count(P, high_t), c_last_t = throttle_count(P, last_t);
+        /* (selects, not run-time subscripts: cr[] / ct[] stay in registers) */
+        if (r3) { cr[3] = c_low_r; nr = 4; }
+        if (r4) { if (nr == 3) cr[3] = c_high_r; else cr[4] = c_high_r; nr++; }
+        if (r5) { if (nr == 3) cr[3] = c_last_r; else if (nr == 4) cr[4] = c_last_r; else cr[5] = c_last_r; nr++; }
+        if (t2) { ct[2] = c_low_t; nt = 3; }
+        if (t3) { if (nt == 2) ct[2] = c_high_t; else ct[3] = c_high_t; nt++; }
+        if (t4) { if (nt == 2) ct[2] = c_last_t; else if (nt == 3) ct[3] = c_last_t; else ct[4] = c_last_t; nt++; }
+        uint32_t at = a - base;
+        if (b - a == nr * nt) {                                       /* (always: the scan counted the same set) */
+#pragma unroll
+            for (uint32_t ti = 0; ti < 5; ti++) {
+#pragma unroll
+                for (uint32_t ri = 0; ri < 6; ri++) {
+                    if (ti < nt && ri < nr) s_cnt[at++] = (uint8_t)(cr[ri] * ct[ti]);   /* throttle outer, rudder inner (controller.cpp:174-182) */
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = base + threadIdx.x; c < end; c += 256) {
+        if (flags[c >> 8]) { B.count[c] = s_cnt[c - base]; B.margin[c] = MARGIN_GHOST; }
     }
 }
 
@@ -1192,6 +1246,7 @@ void mpc_tree_free(mpc_hip_handle *h)
     (void)hipFree(h->d_bpar); h->d_bpar = nullptr; h->cap_bpar = 0;
     (void)hipFree(h->d_tile_list); h->d_tile_list = nullptr; h->cap_tile_list = 0;
     (void)hipFree(h->d_tree_seed); h->d_tree_seed = nullptr;
+    (void)hipFree(h->d_tile_flags); h->d_tile_flags = nullptr; h->cap_tile_flags = 0;
     (void)hipFree(h->d_tree_meta); h->d_tree_meta = nullptr;
     (void)hipHostFree(h->h_tree_meta); h->h_tree_meta = nullptr;
 }
@@ -1248,6 +1303,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     if (int s = publish_level(h, 0)) return s;
 
     h->tree_stopped_by_width = false;
+    int ghost_level = -1;                     /* the level (if any) that was expanded with ghosts: h->d_tile_flags are its tiles' */
     int completed = 0;
     uint64_t best_leaf = 0, steps = 0, evaluated = 0;
     bool leaf_stored = true, overflow = false, stop = false;
@@ -1446,7 +1502,8 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(1), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
                                    2u, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, (const uint32_t *)h->d_tile_list + 1, 2u);
             hipLaunchKernelGGL(tile_select_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, ptrs(A), n, h->d_bpar, n_tiles,
-                               (const uint64_t *)d_bound, h->d_tile_list + 4, h->d_tile_list);
+                               (const uint64_t *)d_bound, h->d_tile_list + 4, h->d_tile_list,
+                               ghost_level == it && A.first == 0 ? (const uint32_t *)h->d_tile_flags : (const uint32_t *)nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_tile_list, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1455,7 +1512,6 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             if (listed > 0 && listed <= n_tiles) { d_list = h->d_tile_list + 4; n_tiles = listed; }      /* (0: cannot happen -- the seed's own tile is listed) */
         }
         /* the level above a final level (the last one asked for comes next): its tiles of ghosts (ghost_select_kernel) */
-        const uint32_t *d_ghost = nullptr;
         static const bool ghosts_on = !(getenv("MPC_HIP_TREE_GHOSTS") && atoi(getenv("MPC_HIP_TREE_GHOSTS")) == 0);   /* diagnostic: 0 = none */
         if (stored && ghosts_on && it + 2 == max_levels && completed == it && it >= 1 && n_tiles >= list_min) {
             if ((size_t)n_tiles + 4 > h->cap_tile_list) {
@@ -1464,6 +1520,12 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
                 HIP_TRY(hipMalloc(&h->d_tile_list, sizeof(uint32_t) * ((size_t)n_tiles + 4)));
                 h->cap_tile_list = (size_t)n_tiles + 4;
             }
+            if ((size_t)n_tiles > h->cap_tile_flags) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                (void)hipFree(h->d_tile_flags); h->d_tile_flags = nullptr; h->cap_tile_flags = 0;
+                HIP_TRY(hipMalloc(&h->d_tile_flags, sizeof(uint32_t) * (size_t)n_tiles));
+                h->cap_tile_flags = (size_t)n_tiles;
+            }
             if (!h->d_tree_seed) HIP_TRY(hipMalloc(&h->d_tree_seed, sizeof(double) * 2));
             const uint64_t lead = best_leaf >= A.first && best_leaf - A.first < n ? best_leaf - A.first : n / 2;
             HIP_TRY(hipMemsetAsync(h->d_tile_list, 0, sizeof(uint32_t), h->stream));
@@ -1471,14 +1533,24 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
                 hipLaunchKernelGGL(tree_greedy_seed_kernel<true>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)lead, it,
                                    (double)MPC_REFINE_REL, h->d_tree_seed);
                 hipLaunchKernelGGL(ghost_select_kernel<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
-                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_list + 4, h->d_tile_list);
+                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list);
             } else {
                 hipLaunchKernelGGL(tree_greedy_seed_kernel<false>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)lead, it,
                                    0.0, h->d_tree_seed);
                 hipLaunchKernelGGL(ghost_select_kernel<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
-                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_list + 4, h->d_tile_list);
+                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list);
             }
-            d_ghost = h->d_tile_list + 4;
+            hipLaunchKernelGGL(ghost_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B),
+                               (const uint32_t *)h->d_tile_flags);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_tile_list, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            uint32_t real = 0;
+            memcpy(&real, h->h_pair, sizeof real);
+            /* (no real tile cannot happen: the greedy descent's own children are not ghosts) */
+            if (real == 0 || real > n_tiles) { mpc_set_err("solve_tree: ghost selection listed no tile"); return MPC_ERR_HIP; }
+            d_list = h->d_tile_list + 4; n_tiles = real;
+            ghost_level = it + 1;
         }
         const uint32_t tpb = std::min<uint32_t>(EXPAND_TILES, std::max<uint32_t>(1, n_tiles / 4096));   /* >= 4096 workgroups first */
         const uint32_t nblk = (n_tiles + tpb - 1) / tpb;
@@ -1487,7 +1559,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             if (stored)
                 hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
                                    nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
-                                   d_ghost, 0u);
+                                   d_list, n_tiles);
             else
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
                                    nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
@@ -1497,7 +1569,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
-                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, d_ghost, 0u);
+                                   tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, d_list, n_tiles);
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
                                    tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, d_list, n_tiles);
