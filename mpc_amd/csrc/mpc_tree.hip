@@ -144,7 +144,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(const uint32_t *_
     __shared__ uint32_t sh[SCAN_BLOCK];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
-    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) s += in[base + j];
+    if (base + SCAN_ITEMS <= n && ((uintptr_t)(in + base) & 15u) == 0) {  /* eight counts as two 16-byte loads (a sliced level may start anywhere) */
+        const uint4 lo = reinterpret_cast<const uint4 *>(in + base)[0], hi = reinterpret_cast<const uint4 *>(in + base)[1];
+        s = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
+    } else {
+        for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) s += in[base + j];
+    }
     uint32_t total;
     block_exclusive_scan(s, sh, total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
@@ -186,16 +191,32 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *
     __shared__ uint32_t sh[SCAN_BLOCK];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS], s = 0;
-    for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? in[base + j] : 0; s += v[j]; }
+    const bool whole = base + SCAN_ITEMS <= n && (((uintptr_t)(in + base) | (uintptr_t)(out + base)) & 15u) == 0;   /* (a sliced level may start anywhere) */
+    if (whole) {                                                       /* two 16-byte loads, two 16-byte stores */
+        const uint4 lo = reinterpret_cast<const uint4 *>(in + base)[0], hi = reinterpret_cast<const uint4 *>(in + base)[1];
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) s += v[j];
+    } else {
+        for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? in[base + j] : 0; s += v[j]; }
+    }
     uint32_t total;
     uint32_t run = block_exclusive_scan(s, sh, total) + sums[blockIdx.x];
+    uint32_t o[SCAN_ITEMS];
+#pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
+        o[j] = run;
         if (base + j < n) {
-            out[base + j] = run;
             const uint64_t q = ((uint64_t)run + 255) >> 8;
             if ((q << 8) < (uint64_t)run + v[j]) bpar[q] = base + j;
         }
         run += v[j];
+    }
+    if (whole) {
+        reinterpret_cast<uint4 *>(out + base)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<uint4 *>(out + base)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+        for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] = o[j];
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = sums[gridDim.x];
 }
