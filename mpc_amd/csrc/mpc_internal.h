@@ -72,6 +72,7 @@ struct TreeLevelBuf {
     size_t cap = 0;
     size_t n = 0;
     size_t first = 0;      /* multi-GPU shard: the level is the slice [first, first + n) of the full level */
+    size_t full_n = 0;     /* the full level's nodes, as expanded (n after a slice is the slice's) */
 };
 
 /* device-side view of one TreeLevelBuf */
@@ -205,6 +206,8 @@ struct mpc_hip_handle {
     uint32_t *d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;
     uint32_t *d_bpar = nullptr; size_t cap_bpar = 0;              /* first parent of every 256-child workgroup */
     double *d_tree_seed = nullptr;                                /* tree search: [0..1] seed bounds of the last two levels (ghost_select_kernel) */
+    int tree_precision = -1;                                     /* the model whose node records the stored levels hold */
+    int tree_full_upto = 0;                                      /* levels 0..this are stored in full (no slice, no ghosts) by the last search */
     bool tree_stopped_by_width = false;                          /* the last tree search ended because the next level does not fit one expansion */
     uint32_t *d_tile_flags = nullptr; size_t cap_tile_flags = 0; /* tree search: ghost flag per tile of the level above the final one */
     uint32_t *d_tile_list = nullptr; size_t cap_tile_list = 0;   /* tree search, final level: [0] count, [1..2] seed tiles, [4..] the short list */

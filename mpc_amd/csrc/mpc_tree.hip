@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(256) void tile_select_kernel(LevelPtrs A, uint32_t 
  * (or a ghost's child) scores above the near-tie window of the seed. */
 template <bool FAST>
 __global__ __launch_bounds__(64) void tree_greedy_seed_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t lead, int level,
-                                                              double refine_rel, double *__restrict__ seed)
+                                                              double refine_rel, double *__restrict__ seed, uint64_t *bound)
 {
     __shared__ __attribute__((aligned(16))) double lds[MPC_MAX_DEPTH * CP_STRIDE + MPC_MAX_SUBSTEPS * SUB_STRIDE];
     __shared__ double rec[12];                                        /* the best child as a one-node level */
@@ -1128,6 +1128,7 @@ __global__ __launch_bounds__(64) void tree_greedy_seed_kernel(const DevProblem *
             }
             seed[q] = dmax;
         }
+        tree_bound_update(bound, k2, P, rel);                         /* the final level starts with the grandchild's score as its bound */
     }
 }
 
@@ -1297,11 +1298,21 @@ static int publish_level(mpc_hip_handle *h, int l)
     return MPC_OK;
 }
 
+/* resume (mpc_hip_solve_tree_deep): levels 0..level of the last search on this handle -- same problem, stored in full
+ * (h->tree_full_upto) -- are taken as they are and the search goes on from there; best_leaf = that level's winner;
+ * store_last: the last level asked for IS stored and nothing is expanded from it (extending the stored part) */
+struct TreeResume { int level; uint64_t best_leaf; bool store_last; };
+
 static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
                            mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
                            int split_level, uint32_t shard, uint32_t n_shards,
-                           mpc_tree_level *h_level_best, mpc_result *h_result)
+                           mpc_tree_level *h_level_best, mpc_result *h_result, const TreeResume *resume = nullptr)
 {
+    if (resume && (resume->level < 1 || resume->level > h->tree_full_upto || precision != h->tree_precision || resume->level >= max_levels + (resume->store_last ? 1 : 0) ||
+                   (n_shards > 1 && split_level != resume->level))) {
+        mpc_set_err("solve_tree: nothing stored to resume from");
+        return MPC_ERR_INVALID;
+    }
     const bool fast = precision == MPC_PREC_FAST;
     memset(h_result, 0, sizeof *h_result);
     const bool own_cap = max_nodes == 0;      /* no caller budget: the library's own storage cap */
@@ -1319,14 +1330,22 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     h->timed[h->runs % TIMING_RING] = 1;
     h->total_from_k1[h->runs % TIMING_RING] = 0;
     HIP_TRY(hipEventRecord(ev[0], h->stream));
-    if (int s = ensure_level(h, h->tree[0], 1)) return s;
-    h->tree[0].n = 1;
-    if (int s = publish_level(h, 0)) return s;
+    if (!resume) {
+        if (int s = ensure_level(h, h->tree[0], 1)) return s;
+        h->tree[0].n = h->tree[0].full_n = 1;
+        if (int s = publish_level(h, 0)) return s;
+        h->tree_full_upto = 0;
+        h->tree_precision = precision;
+    } else {
+        h->tree[resume->level].n = h->tree[resume->level].full_n;          /* (a piece before this one left its slice there) */
+        if (int s = publish_level(h, resume->level)) return s;
+        h->tree_full_upto = resume->level;
+    }
 
     h->tree_stopped_by_width = false;
     int ghost_level = -1;                     /* the level (if any) that was expanded with ghosts: h->d_tile_flags are its tiles' */
-    int completed = 0;
-    uint64_t best_leaf = 0, steps = 0, evaluated = 0;
+    int completed = resume ? resume->level : 0;
+    uint64_t best_leaf = resume ? resume->best_leaf : 0, steps = 0, evaluated = 0;
     bool leaf_stored = true, overflow = false, stop = false;
     uint32_t last_tie = 0;
     auto record_level = [&](int it, uint64_t nchild, const uint64_t *w, bool stored, uint64_t tie) {
@@ -1348,7 +1367,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
      * (DFS order is preserved within and across shards) */
     auto slice_level = [&](int level, bool stored) -> int {
         TreeLevelBuf &B = h->tree[level];
-        const uint64_t nchild = B.n;
+        const uint64_t nchild = B.full_n;
         if (!stored) { mpc_set_err("solve_tree_shard: split_level must be below max_levels"); return MPC_ERR_INVALID; }
         if (nchild < n_shards) { mpc_set_err("solve_tree_shard: the split level has fewer nodes than shards"); return MPC_ERR_INVALID; }
         const uint64_t base = nchild / n_shards, extra = nchild % n_shards;
@@ -1366,8 +1385,9 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         /* a caller's node budget bounds memory and work: only levels whose 30^l bound fits it are expanded blind (their
          * buffers and grids are sized for the bound); the levels beyond go the synchronised way, which sizes by the real
          * counts and stops at the budget before allocating */
-        while (!sync_levels && blind < lim && bound * 30 <= BLIND_MAX_NODES && (own_cap || bound * 30 <= max_nodes)) { bound *= 30; blind++; }
+        while (!resume && !sync_levels && blind < lim && bound * 30 <= BLIND_MAX_NODES && (own_cap || bound * 30 <= max_nodes)) { bound *= 30; blind++; }
     }
+    if (resume && n_shards > 1) { if (int s = slice_level(resume->level, true)) return s; }
     if (now && now(now_ctx) >= end_time) blind = 0;                       /* the loop below breaks at once */
     if (!h->d_tree_meta) {
         HIP_TRY(hipMalloc(&h->d_tree_meta, sizeof(uint64_t) * (TREE_META * (MPC_MAX_DEPTH + 2) + 2)));   /* + the pruning bound's two words */
@@ -1397,9 +1417,11 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     }
     /* the pruning bound of the unstored final level (tree_bound_update): "none yet" = all ones (as a double: NaN) */
     uint64_t *d_bound = h->d_tree_meta + TREE_META * (MPC_MAX_DEPTH + 2);
-    HIP_TRY(hipMemsetAsync(d_bound, 0xFF, sizeof(uint64_t) * 2, h->stream));
-    hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]), (int)fast, h->d_bpar,
-                       blind > 0 ? h->d_tree_meta : (uint64_t *)nullptr);
+    /* (the pieces of a resumed search look for the level's ONE winner: what an earlier piece found bounds the later ones) */
+    if (!(resume && n_shards > 1 && shard > 0)) HIP_TRY(hipMemsetAsync(d_bound, 0xFF, sizeof(uint64_t) * 2, h->stream));
+    if (!resume)
+        hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, h->stream, h->d_probs, ptrs(h->tree[0]), (int)fast, h->d_bpar,
+                           blind > 0 ? h->d_tree_meta : (uint64_t *)nullptr);
     HIP_TRY(hipGetLastError());
     if (blind > 0) {
         uint64_t pb = 1;
@@ -1444,14 +1466,15 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             if (!own_cap && nchild > max_nodes) { stop = true; break; }   /* wider than the caller's budget: ends the search */
             if (fast && m[5]) { overflow = true; break; }                 /* > LIST_CAP tied leaves: the strict expansion decides */
             if (now && t_after >= end_time && t_after - (double)(clk_ref - m[6]) * 1.0e-8 >= end_time) { stop = true; break; }
-            h->tree[it + 1].n = stored ? nchild : 1;
+            h->tree[it + 1].n = h->tree[it + 1].full_n = stored ? nchild : 1;
+            if (stored && (n_shards == 1 || it + 1 <= split_level)) h->tree_full_upto = it + 1;
             record_level(it, nchild, m + 1, stored, m[7]);
             if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
             if (!stored) { stop = true; break; }
         }
         if (completed < blind) stop = true;
     }
-    for (int it = blind; it < max_levels && !stop && !overflow; it++) {
+    for (int it = resume ? resume->level : blind; it < max_levels && !stop && !overflow; it++) {
         if (now && now(now_ctx) >= end_time) break;                       /* controller.cpp:101-103 */
         TreeLevelBuf &A = h->tree[it];
         const uint32_t n = (uint32_t)A.n;
@@ -1489,13 +1512,13 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         TreeLevelBuf &B = h->tree[it + 1];
         /* the last level asked for is never a parent level: expanded without stores (strict: into a one-node buffer
          * that receives the winner's record; fast: the winner comes from its path) */
-        const bool stored = it + 1 < max_levels && !too_wide;
+        const bool stored = (it + 1 < max_levels || (resume && resume->store_last)) && !too_wide;
         B.first = 0;
         if (int s = ensure_level(h, B, stored ? nchild : 1)) {
             if (s == MPC_ERR_HIP) { (void)hipGetLastError(); break; }     /* out of memory: stop like a deadline */
             return s;
         }
-        B.n = nchild;
+        B.n = B.full_n = nchild;
         if (int s = publish_level(h, it + 1)) return s;
         uint32_t n_tiles = (nchild + 255) / 256;
         if (int s = mpc_ensure_partials(h, (n_tiles + EXPAND_TILES - 1) / EXPAND_TILES + 4096)) return s;
@@ -1504,6 +1527,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         static const uint32_t list_min = getenv("MPC_HIP_TREE_LIST_MIN") ? (uint32_t)strtoul(getenv("MPC_HIP_TREE_LIST_MIN"), nullptr, 10) : TILE_LIST_MIN;
         /* a wide final level: the short list of its tiles (seed_tiles_kernel / tile_select_kernel above) */
         const uint32_t *d_list = nullptr;
+        bool empty_level = false;              /* no node of the level can matter: nothing is expanded, nothing selected */
         if (!stored && n_tiles >= list_min) {
             if ((size_t)n_tiles + 4 > h->cap_tile_list) {
                 HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1530,7 +1554,9 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             HIP_TRY(hipStreamSynchronize(h->stream));
             uint32_t listed = 0;
             memcpy(&listed, h->h_pair, sizeof listed);
-            if (listed > 0 && listed <= n_tiles) { d_list = h->d_tile_list + 4; n_tiles = listed; }      /* (0: cannot happen -- the seed's own tile is listed) */
+            if (listed > n_tiles) { mpc_set_err("solve_tree: tile selection overran its list"); return MPC_ERR_HIP; }
+            /* (nothing listed: no tile within reach of a bound that came from elsewhere -- an earlier piece, the greedy descent) */
+            d_list = h->d_tile_list + 4; n_tiles = listed; empty_level = listed == 0;
         }
         /* the level above a final level (the last one asked for comes next): its tiles of ghosts (ghost_select_kernel) */
         static const bool ghosts_on = !(getenv("MPC_HIP_TREE_GHOSTS") && atoi(getenv("MPC_HIP_TREE_GHOSTS")) == 0);   /* diagnostic: 0 = none */
@@ -1548,16 +1574,21 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
                 h->cap_tile_flags = (size_t)n_tiles;
             }
             if (!h->d_tree_seed) HIP_TRY(hipMalloc(&h->d_tree_seed, sizeof(double) * 2));
-            const uint64_t lead = best_leaf >= A.first && best_leaf - A.first < n ? best_leaf - A.first : n / 2;
+            /* the greedy descent starts from the level's winner: of this shard's slice where it lies in it (else the middle
+             * node), of the WHOLE level in a resumed search -- the level above the slice is there in full, and the pieces
+             * look for the level's one winner, so a score from anywhere bounds them */
+            TreeLevelBuf lead_view = A;
+            uint64_t lead = best_leaf >= A.first && best_leaf - A.first < n ? best_leaf - A.first : n / 2;
+            if (resume && it == resume->level) { lead_view.first = 0; lead = resume->best_leaf < A.full_n ? resume->best_leaf : A.first + n / 2; }
             HIP_TRY(hipMemsetAsync(h->d_tile_list, 0, sizeof(uint32_t), h->stream));
             if (fast) {
-                hipLaunchKernelGGL(tree_greedy_seed_kernel<true>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)lead, it,
-                                   (double)MPC_REFINE_REL, h->d_tree_seed);
+                hipLaunchKernelGGL(tree_greedy_seed_kernel<true>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(lead_view), (uint32_t)lead, it,
+                                   (double)MPC_REFINE_REL, h->d_tree_seed, d_bound);
                 hipLaunchKernelGGL(ghost_select_kernel<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
                                    h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list);
             } else {
-                hipLaunchKernelGGL(tree_greedy_seed_kernel<false>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), (uint32_t)lead, it,
-                                   0.0, h->d_tree_seed);
+                hipLaunchKernelGGL(tree_greedy_seed_kernel<false>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(lead_view), (uint32_t)lead, it,
+                                   0.0, h->d_tree_seed, d_bound);
                 hipLaunchKernelGGL(ghost_select_kernel<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
                                    h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list);
             }
@@ -1568,15 +1599,18 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             HIP_TRY(hipStreamSynchronize(h->stream));
             uint32_t real = 0;
             memcpy(&real, h->h_pair, sizeof real);
-            /* (no real tile cannot happen: the greedy descent's own children are not ghosts) */
-            if (real == 0 || real > n_tiles) { mpc_set_err("solve_tree: ghost selection listed no tile"); return MPC_ERR_HIP; }
-            d_list = h->d_tile_list + 4; n_tiles = real;
+            if (real > n_tiles) { mpc_set_err("solve_tree: ghost selection overran its list"); return MPC_ERR_HIP; }
+            /* (no real tile: a slice all of whose nodes are out of reach of bounds that came from outside it) */
+            d_list = h->d_tile_list + 4; n_tiles = real; empty_level = real == 0;
             ghost_level = it + 1;
         }
         const uint32_t tpb = std::min<uint32_t>(EXPAND_TILES, std::max<uint32_t>(1, n_tiles / 4096));   /* >= 4096 workgroups first */
         const uint32_t nblk = (n_tiles + tpb - 1) / tpb;
         if (int s = mpc_ensure_partials(h, nblk)) return s;
-        if (fast) {
+        if (empty_level) {
+            /* what the reductions report for a level without a finite score */
+            h->h_pair[0] = KEY_INF; h->h_pair[1] = ~0ull; h->h_pair[2] = KEY_INF; h->h_pair[3] = KEY_INF; h->h_pair[4] = 0; h->h_pair[5] = 0;
+        } else if (fast) {
             if (stored)
                 hipLaunchKernelGGL(expand_fast_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
                                    nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
@@ -1600,11 +1634,15 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * 6, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!empty_level) {
+            HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * 6, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
         if (fast && h->h_pair[4]) { overflow = true; break; }            /* > LIST_CAP tied leaves: the strict expansion decides */
         if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
         record_level(it, nchild, h->h_pair, stored, h->h_pair[5]);
+        /* (stored in full: all children of a full level, none of them a ghost) */
+        if (stored && ghost_level != it + 1 && h->tree_full_upto == it && !(n_shards > 1 && it >= split_level)) h->tree_full_upto = it + 1;
         if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
         if (!stored) { h->tree_stopped_by_width = too_wide; break; }     /* nothing to expand the next level from */
     }
@@ -1618,6 +1656,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         HIP_TRY(hipEventRecord(ev[3], h->stream));
         h->runs++;
         h_result->status = MPC_ERR_NO_ITERATION;                          /* controller.cpp:196 */
+        h_result->levels = resume ? completed : 0;                        /* (a piece that holds nothing within reach of the level's winner still counted its leaves) */
         return MPC_ERR_NO_ITERATION;
     }
     if (fast) {
@@ -1662,7 +1701,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
 static int solve_tree_checked(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
                               mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
                               int split_level, uint32_t shard, uint32_t n_shards,
-                              mpc_tree_level *h_level_best, mpc_result *h_result)
+                              mpc_tree_level *h_level_best, mpc_result *h_result, const TreeResume *resume = nullptr)
 {
     if (!h || !h_problem || !h_result) { mpc_set_err("solve_tree: NULL argument"); return MPC_ERR_INVALID; }
     if (precision != MPC_PREC_F64 && precision != MPC_PREC_FAST) { mpc_set_err("unknown precision"); return MPC_ERR_INVALID; }
@@ -1686,10 +1725,13 @@ static int solve_tree_checked(mpc_hip_handle *h, const mpc_problem *h_problem, i
         return MPC_ERR_NO_ITERATION;
     }
     int s = solve_tree_once(h, h_problem, max_levels, precision, now, now_ctx, end_time, max_nodes, split_level, shard,
-                            n_shards, h_level_best, h_result);
-    if (s == MPC_INTERNAL_RERUN_STRICT)
+                            n_shards, h_level_best, h_result, resume);
+    if (s == MPC_INTERNAL_RERUN_STRICT) {
+        /* (a resumed search has the fast expansion's node records above it: the strict one cannot go on from those) */
+        if (resume) { mpc_set_err("solve_tree: too many tied leaves in a resumed search"); return MPC_ERR_INVALID; }
         s = solve_tree_once(h, h_problem, max_levels, MPC_PREC_F64, now, now_ctx, end_time, max_nodes, split_level, shard,
                             n_shards, h_level_best, h_result);
+    }
     return s;
 }
 
@@ -1725,28 +1767,42 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
     const uint64_t nsub = (uint64_t)h_problem->n_substeps;
     std::vector<mpc_tree_level> plv((size_t)std::max(max_levels, 1));
     std::vector<mpc_result> keep(2);                          /* [0] the best piece so far, [1] the piece just searched */
-    while (L < max_levels && h->tree_stopped_by_width) {
+    bool wide = h->tree_stopped_by_width;
+    while (L < max_levels && wide) {
         if (now && now(now_ctx) >= end_time) break;
-        const int target = L + 1;
-        /* pieces: contiguous slices of a shallow level's nodes, so many that a piece's leaves fit 32-bit ordinals and its
-         * slice of level L fits the storage cap */
-        /* (the next level's size: the last level's growth, at most 30-fold, and half as much again for uneven subtrees; a
+        /* Level `target` is searched from the nodes of level target - 2, which must be there in full: a piece takes a
+         * contiguous slice of them, gives their children (level target - 1) ghosts' treatment and searches the final level.
+         * Nothing above the slice is expanded again (TreeResume).  After the plain search level L - 1 is in full; one level
+         * further down it has to be stored first -- in full, no ghosts: 3.0e8 nodes, 10 ms, 32 GB for depth 9. */
+        const int target = L + 1, need = target - 2, prec = h->tree_precision;
+        if (need < 1) break;
+        if (h->tree_full_upto < need) {
+            if (h->tree_full_upto < 1) break;
+            const TreeResume ext{h->tree_full_upto, lv[(size_t)h->tree_full_upto - 1].best_leaf, true};
+            s = solve_tree_checked(h, h_problem, need, prec, now, now_ctx, end_time, 1ull << 30, 0, 0, 1, plv.data(), &keep[1], &ext);
+            if (s != MPC_OK || h->tree_full_upto < need) break;                  /* the clock, memory, or a level beyond 32-bit indices */
+        }
+        /* pieces: so many that a piece's leaves fit 32-bit ordinals and its slice of level target - 1 the storage cap
+         * (the next level's size: the last level's growth, at most 30-fold, and half as much again for uneven subtrees; a
          * piece that does not fit after all shows at its own scan, and the level is started over with twice the pieces) */
         const double leaves_L = (double)lv[(size_t)L - 1].n_leaves;
         const double growth = L >= 2 ? std::min(30.0, leaves_L / (double)std::max<uint64_t>(lv[(size_t)L - 2].n_leaves, 1)) : 30.0;
         uint32_t pieces = (uint32_t)std::max(2.0, ceil(std::max(leaves_L * growth * 1.5 / 4.0e9, leaves_L * 1.5 / (double)(1u << 28))));
+        const TreeResume from{need, lv[(size_t)need - 1].best_leaf, false};
         bool done = false, abandoned = false;
         for (int attempt = 0; attempt < 3 && !done && !abandoned; attempt++, pieces *= 2) {
-            int split = 1;
-            while (split < L - 1 && lv[(size_t)split - 1].n_leaves < 64ull * pieces) split++;
-            if (lv[(size_t)split - 1].n_leaves < pieces) { abandoned = true; break; }
+            if (lv[(size_t)need - 1].n_leaves < pieces) { abandoned = true; break; }
             uint64_t total = 0, best_key = ~0ull, best_ord = ~0ull, runner_up = ~0ull;
             uint32_t tie = 0;
             double k_ms = 0, t_ms = 0;
             bool refit = false;
             for (uint32_t piece = 0; piece < pieces; piece++) {
                 if (now && now(now_ctx) >= end_time) { abandoned = true; break; }    /* controller.cpp:101-103: an unfinished iteration does not count */
-                s = solve_tree_checked(h, h_problem, target, precision, now, now_ctx, end_time, 0, split, piece, pieces, plv.data(), &keep[1]);
+                s = solve_tree_checked(h, h_problem, target, prec, now, now_ctx, end_time, 0, need, piece, pieces, plv.data(), &keep[1], &from);
+                if (s == MPC_ERR_NO_ITERATION && keep[1].levels == target) {         /* nothing in this piece can win: its leaves only count */
+                    total += plv[(size_t)target - 1].n_leaves;
+                    continue;
+                }
                 if (s != MPC_OK) { abandoned = true; break; }
                 if (keep[1].levels < target) {                                        /* the clock, or a piece that still does not fit */
                     if (h->tree_stopped_by_width && !(now && now(now_ctx) >= end_time)) refit = true; else abandoned = true;
@@ -1791,7 +1847,6 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
             if (h_level_best) h_level_best[target - 1] = out;
             L = target;
             done = true;
-            h->tree_stopped_by_width = true;                                          /* the next level is wider still */
         }
         if (!done) break;
     }
