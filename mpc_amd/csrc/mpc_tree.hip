@@ -1796,8 +1796,14 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
             uint32_t tie = 0;
             double k_ms = 0, t_ms = 0;
             bool refit = false;
+            const double t_level = now ? now(now_ctx) : 0.0;
             for (uint32_t piece = 0; piece < pieces; piece++) {
-                if (now && now(now_ctx) >= end_time) { abandoned = true; break; }    /* controller.cpp:101-103: an unfinished iteration does not count */
+                if (now) {
+                    /* controller.cpp:101-103: an unfinished iteration does not count -- so a level whose remaining pieces, at
+                     * the pace of those done, would end after the deadline is given up now rather than at the deadline */
+                    const double t = now(now_ctx);
+                    if (t >= end_time || (piece > 0 && t + 0.9 * (t - t_level) / piece * (pieces - piece) >= end_time)) { abandoned = true; break; }
+                }
                 s = solve_tree_checked(h, h_problem, target, prec, now, now_ctx, end_time, 0, need, piece, pieces, plv.data(), &keep[1], &from);
                 if (s == MPC_ERR_NO_ITERATION && keep[1].levels == target) {         /* nothing in this piece can win: its leaves only count */
                     total += plv[(size_t)target - 1].n_leaves;

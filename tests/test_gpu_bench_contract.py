@@ -63,7 +63,7 @@ def test_default_line_has_the_contract_keys():
                 assert row["same_first_control"] is True and row["cpu_ms"] > row["strict_p50_ms"]
         assert sc["depth"]["8"]["leaves"] == 5172889071            # beyond one expansion: mpc_hip_solve_tree_deep, in pieces
         # the whole depth-8 search fits the reference's 0.1-s budget on one GPU, in both expansions
-        assert sc["deepest_level_inside_budget"]["fast"]["levels"] == 8 and sc["deepest_level_inside_budget"]["strict"]["levels"] == 8
+        assert sc["deepest_level_inside_budget"]["fast"]["levels"] >= 8 and sc["deepest_level_inside_budget"]["strict"]["levels"] >= 8
         assert sc["cpu_deepest_level_inside_budget"] <= 5
     assert t["scenarios"]["lrl_semicircle"]["depth"]["4"]["first_control"] == [-0.0625, 1.0]     # SURVEY.md 8c's probe of the reference
 
