@@ -184,7 +184,7 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
         Lease lease;
         /* Which model EXPANDS the tree; whichever it is, the strict model decides every level and the returned states
          * are the strict path's (same leaf, same bits: tests/test_gpu_tree.py).  The streamlined model is sooner from
-         * depth 6 on (depth 7: 1.3 ms against 1.7 ms, depth 8: 12 ms against 18 ms), the strict one below (depth 4: 0.11 ms against 0.19 ms), so the
+         * depth 6 on (depth 7: 1.1 ms against 1.4 ms, depth 8: 7 ms against 11 ms), the strict one below (depth 4: 0.11 ms against 0.19 ms), so the
          * plan's length chooses; MPC_HIP_TREE_PRECISION=fast|strict (or f64) in the environment overrides. */
         static const int forced = [] {
             const char *e = getenv("MPC_HIP_TREE_PRECISION");
@@ -194,7 +194,7 @@ Controller::MpcState Controller::mpc(State startState, const DubinsPlan& referen
         }();
         const int precision = forced >= 0 ? forced : (maxIterations > 5 ? (int)MPC_PREC_FAST : (int)MPC_PREC_F64);
         /* (the _deep entry point is mpc_hip_solve_tree for as long as one expansion holds a level -- depth 7 with the default
-         * control sets, ~1.5 ms -- and then goes on a level at a time in pieces while the clock allows: depth 8 in 12-15 ms) */
+         * control sets, ~1.5 ms -- and then goes on a level at a time in pieces while the clock allows: depth 8 in 7-11 ms) */
         status = mpc_hip_solve_tree_deep(lease.h, &problem, maxIterations, precision, poll, &ctx, endTime, nullptr, &result);
     }
     if (ctx.cancelled) return {};                                                             /* :83-86 */
