@@ -420,14 +420,16 @@ int         mpc_hip_solve_tree_shard(mpc_hip_handle *h, const mpc_problem *h_pro
 
 /* The reference's deepening loop (controller.cpp:80) has no depth limit but its clock; one expansion has two: 32-bit leaf
  * ordinals and the storage cap.  With the default control sets they end mpc_hip_solve_tree at depth 7 (3.0e8 leaves) --
- * in ~2 ms of the 100 ms the planner grants.  This entry point goes on from there: each further level is searched in
+ * in ~1.5 ms of the 100 ms the planner grants.  This entry point goes on from there: each further level is searched in
  * pieces -- slices of the deepest level that is stored in full, searched one after the other on this handle without
- * expanding anything above them again, as many as make a piece's leaves fit -- and the pieces' winners are combined as the shards' are: the smallest (strict score, global DFS ordinal).  Depth 8 (5.2e9 leaves) takes
- * 7-11 ms (MPC_PREC_FAST) on one MI355X, depth 9 (8.8e10) 93-132 ms.  A level counts only if all its pieces finished before end_time
- * (controller.cpp:101-103: an unfinished iteration is discarded); h_level_best / h_result then stay the previous
- * level's -- and the level is given up as soon as its remaining pieces, at the pace of those done, would end after it.  now == NULL runs to max_levels whatever that takes.  Results are those of one search of the same depth: same
- * leaf, same scores, same trajectory; best_ordinal and h_level_best[].best_leaf are 64-bit DFS ordinals of the whole level.
- * Replaces the same lines of the reference as mpc_hip_solve_tree (controller.cpp:80-189). */
+ * expanding anything above them again, as many as make a piece's leaves fit -- and the pieces' winners are combined as
+ * the shards' are: the smallest (strict score, global DFS ordinal).  Depth 8 (5.2e9 leaves) takes 7-11 ms
+ * (MPC_PREC_FAST) on one MI355X, depth 9 (8.8e10) 93-132 ms.  A level counts only if all its pieces finished before
+ * end_time (controller.cpp:101-103: an unfinished iteration is discarded); h_level_best / h_result then stay the
+ * previous level's -- and the level is given up as soon as its remaining pieces, at the pace of those done, would end
+ * after it.  now == NULL runs to max_levels whatever that takes.  Results are those of one search of the same depth:
+ * same leaf, same scores, same trajectory; best_ordinal and h_level_best[].best_leaf are 64-bit DFS ordinals of the
+ * whole level.  Replaces the same lines of the reference as mpc_hip_solve_tree (controller.cpp:80-189). */
 int         mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels,
                                     int precision, mpc_time_fn now, void *now_ctx, double end_time,
                                     mpc_tree_level *h_level_best, mpc_result *h_result);
