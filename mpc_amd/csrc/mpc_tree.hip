@@ -1138,7 +1138,8 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void ghost_select_kernel(const DevProblem *__restrict__ probs, LevelPtrs A, uint32_t n_parent,
                                                            const uint32_t *__restrict__ bpar, uint32_t n_tiles, int level,
                                                            const double *__restrict__ seed, uint32_t *__restrict__ flags,
-                                                           uint32_t *__restrict__ real_list, uint32_t *__restrict__ real_tiles)
+                                                           uint32_t *__restrict__ real_list, uint32_t *__restrict__ real_tiles,
+                                                           int children_decided)
 {
     __shared__ uint32_t s_f[256];
     const DevProblem &P = probs[0];
@@ -1151,7 +1152,7 @@ __global__ __launch_bounds__(256) void ghost_select_kernel(const DevProblem *__r
     for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += 256) {
         const uint32_t a = A.offset[p], b = A.offset[p + 1];
         if (b <= a) continue;
-        bool ghosts = margin_beyond(A.margin[p], dm1);
+        bool ghosts = children_decided || margin_beyond(A.margin[p], dm1);   /* (the children's own level may have its record already) */
         if (ghosts) {
             float m2;
             if (FAST) m2 = node_margin<2>(P, c2[6], c2[7], A.x[p], A.y[p], A.v[p], A.rpm[p], A.h[p], A.cmg[p]);
@@ -1301,7 +1302,12 @@ static int publish_level(mpc_hip_handle *h, int l)
 /* resume (mpc_hip_solve_tree_deep): levels 0..level of the last search on this handle -- same problem, stored in full
  * (h->tree_full_upto) -- are taken as they are and the search goes on from there; best_leaf = that level's winner;
  * store_last: the last level asked for IS stored and nothing is expanded from it (extending the stored part) */
-struct TreeResume { int level; uint64_t best_leaf; bool store_last; };
+struct TreeResume {
+    int level; uint64_t best_leaf; bool store_last;
+    bool record_known;      /* the record of level + 1 is known already (a shallower search found it): its nodes matter as parents only
+                             * -- ghosts by their grandchildren alone, no reduction of that level */
+    uint64_t beat_key;      /* the final level's best score so far (KEY_INF: none): a search that does not beat it returns no trajectory */
+};
 
 static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int max_levels, int precision,
                            mpc_time_fn now, void *now_ctx, double end_time, uint64_t max_nodes,
@@ -1348,6 +1354,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
     uint64_t best_leaf = resume ? resume->best_leaf : 0, steps = 0, evaluated = 0;
     bool leaf_stored = true, overflow = false, stop = false;
     uint32_t last_tie = 0;
+    uint64_t last_key = KEY_INF;              /* the deepest completed level's winning score (sync path) */
     auto record_level = [&](int it, uint64_t nchild, const uint64_t *w, bool stored, uint64_t tie) {
         completed = it + 1;
         best_leaf = w[1];
@@ -1560,6 +1567,7 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         }
         /* the level above a final level (the last one asked for comes next): its tiles of ghosts (ghost_select_kernel) */
         static const bool ghosts_on = !(getenv("MPC_HIP_TREE_GHOSTS") && atoi(getenv("MPC_HIP_TREE_GHOSTS")) == 0);   /* diagnostic: 0 = none */
+        const bool known_record = resume && resume->record_known && it == resume->level && stored;
         if (stored && ghosts_on && it + 2 == max_levels && completed == it && it >= 1 && n_tiles >= list_min) {
             if ((size_t)n_tiles + 4 > h->cap_tile_list) {
                 HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1585,12 +1593,14 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
                 hipLaunchKernelGGL(tree_greedy_seed_kernel<true>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(lead_view), (uint32_t)lead, it,
                                    (double)MPC_REFINE_REL, h->d_tree_seed, d_bound);
                 hipLaunchKernelGGL(ghost_select_kernel<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
-                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list);
+                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list,
+                                   (int)known_record);
             } else {
                 hipLaunchKernelGGL(tree_greedy_seed_kernel<false>, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(lead_view), (uint32_t)lead, it,
                                    0.0, h->d_tree_seed, d_bound);
                 hipLaunchKernelGGL(ghost_select_kernel<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n,
-                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list);
+                                   h->d_bpar, n_tiles, it, (const double *)h->d_tree_seed, h->d_tile_flags, h->d_tile_list + 4, h->d_tile_list,
+                                   (int)known_record);
             }
             hipLaunchKernelGGL(ghost_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B),
                                (const uint32_t *)h->d_tile_flags);
@@ -1619,8 +1629,9 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
                 hipLaunchKernelGGL(expand_fast_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B),
                                    nchild, it, (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, (const uint64_t *)nullptr, d_bound,
                                    d_list, n_tiles);
-            hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(TREE_FINISH_THREADS), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
-                               (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_bpar, h->d_winners, d_list, n_tiles);
+            if (!known_record)
+                hipLaunchKernelGGL(tree_finish_kernel, dim3(1), dim3(TREE_FINISH_THREADS), 0, h->stream, h->d_probs, h->d_level_ptrs, it, n, nchild,
+                                   (double)MPC_REFINE_REL, tpb, h->d_pkey, h->d_pord, h->d_pcnt, nblk, h->d_bpar, h->d_winners, d_list, n_tiles);
         } else {
             if (stored)
                 hipLaunchKernelGGL(expand_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
@@ -1628,19 +1639,24 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
             else
                 hipLaunchKernelGGL(expand_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, h->d_probs, ptrs(A), n, h->d_bpar, ptrs(B), nchild, it,
                                    tpb, h->d_pkey, h->d_pord, h->d_pkey2, (const uint64_t *)nullptr, d_bound, d_list, n_tiles);
-            hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(TREE_FINISH_THREADS), 0, h->stream, h->d_probs, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
-            if (!stored)
-                hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
-            hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);
+            if (!known_record) {
+                hipLaunchKernelGGL(level_reduce_kernel, dim3(1), dim3(TREE_FINISH_THREADS), 0, h->stream, h->d_probs, h->d_pkey, h->d_pord, h->d_pkey2, nblk, h->d_winners);
+                if (!stored)
+                    hipLaunchKernelGGL(leaf_record_kernel, dim3(1), dim3(64), 0, h->stream, h->d_probs, ptrs(A), n, ptrs(B), it, h->d_winners);
+                hipLaunchKernelGGL(level_scores_kernel, dim3(1), dim3(1), 0, h->stream, ptrs(B), (int)stored, h->d_winners);
+            }
         }
         HIP_TRY(hipGetLastError());
-        if (!empty_level) {
+        if (known_record && !empty_level) {          /* nobody asks for this level's winner again */
+            h->h_pair[0] = KEY_INF; h->h_pair[1] = ~0ull; h->h_pair[2] = KEY_INF; h->h_pair[3] = KEY_INF; h->h_pair[4] = 0; h->h_pair[5] = 0;
+        } else if (!empty_level) {
             HIP_TRY(hipMemcpyAsync(h->h_pair, h->d_winners, sizeof(uint64_t) * 6, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
         if (fast && h->h_pair[4]) { overflow = true; break; }            /* > LIST_CAP tied leaves: the strict expansion decides */
         if (now && now(now_ctx) >= end_time) break;                       /* finished too late: iteration discarded */
         record_level(it, nchild, h->h_pair, stored, h->h_pair[5]);
+        last_key = h->h_pair[0];
         /* (stored in full: all children of a full level, none of them a ghost) */
         if (stored && ghost_level != it + 1 && h->tree_full_upto == it && !(n_shards > 1 && it >= split_level)) h->tree_full_upto = it + 1;
         if (n_shards > 1 && it + 1 == split_level) { if (int s = slice_level(it + 1, stored)) return s; }
@@ -1657,6 +1673,14 @@ static int solve_tree_once(mpc_hip_handle *h, const mpc_problem *h_problem, int 
         h->runs++;
         h_result->status = MPC_ERR_NO_ITERATION;                          /* controller.cpp:196 */
         h_result->levels = resume ? completed : 0;                        /* (a piece that holds nothing within reach of the level's winner still counted its leaves) */
+        return MPC_ERR_NO_ITERATION;
+    }
+    if (resume && completed == max_levels && last_key >= resume->beat_key) {
+        /* a piece whose best does not beat an earlier piece's (ties keep the earlier: DFS order): the same answer, no trajectory */
+        HIP_TRY(hipEventRecord(ev[3], h->stream));
+        h->runs++;
+        h_result->status = MPC_ERR_NO_ITERATION;
+        h_result->levels = completed;
         return MPC_ERR_NO_ITERATION;
     }
     if (fast) {
@@ -1778,7 +1802,7 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
         if (need < 1) break;
         if (h->tree_full_upto < need) {
             if (h->tree_full_upto < 1) break;
-            const TreeResume ext{h->tree_full_upto, lv[(size_t)h->tree_full_upto - 1].best_leaf, true};
+            const TreeResume ext{h->tree_full_upto, lv[(size_t)h->tree_full_upto - 1].best_leaf, true, false, KEY_INF};
             s = solve_tree_checked(h, h_problem, need, prec, now, now_ctx, end_time, 1ull << 30, 0, 0, 1, plv.data(), &keep[1], &ext);
             if (s != MPC_OK || h->tree_full_upto < need) break;                  /* the clock, memory, or a level beyond 32-bit indices */
         }
@@ -1788,7 +1812,7 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
         const double leaves_L = (double)lv[(size_t)L - 1].n_leaves;
         const double growth = L >= 2 ? std::min(30.0, leaves_L / (double)std::max<uint64_t>(lv[(size_t)L - 2].n_leaves, 1)) : 30.0;
         uint32_t pieces = (uint32_t)std::max(2.0, ceil(std::max(leaves_L * growth * 1.5 / 4.0e9, leaves_L * 1.5 / (double)(1u << 28))));
-        const TreeResume from{need, lv[(size_t)need - 1].best_leaf, false};
+        TreeResume from{need, lv[(size_t)need - 1].best_leaf, false, true, KEY_INF};     /* (level target - 1's record: lv[], found before) */
         bool done = false, abandoned = false;
         for (int attempt = 0; attempt < 3 && !done && !abandoned; attempt++, pieces *= 2) {
             if (lv[(size_t)need - 1].n_leaves < pieces) { abandoned = true; break; }
@@ -1804,8 +1828,13 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
                     const double t = now(now_ctx);
                     if (t >= end_time || (piece > 0 && t + 0.9 * (t - t_level) / piece * (pieces - piece) >= end_time)) { abandoned = true; break; }
                 }
+                from.beat_key = best_key < KEY_INF ? best_key : KEY_INF;
                 s = solve_tree_checked(h, h_problem, target, prec, now, now_ctx, end_time, 0, need, piece, pieces, plv.data(), &keep[1], &from);
-                if (s == MPC_ERR_NO_ITERATION && keep[1].levels == target) {         /* nothing in this piece can win: its leaves only count */
+                if (s == MPC_ERR_NO_ITERATION && keep[1].levels == target) {         /* nothing in this piece beats what is found: its leaves only count */
+                    const mpc_tree_level &e = plv[(size_t)target - 1];
+                    uint64_t ek;
+                    memcpy(&ek, &e.best_score, sizeof ek);
+                    if (e.best_score >= 0.0 && ek < KEY_INF) runner_up = std::min(runner_up, ek);   /* (it may still tie: libm_tie) */
                     total += plv[(size_t)target - 1].n_leaves;
                     continue;
                 }
