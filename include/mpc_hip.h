@@ -424,7 +424,7 @@ int         mpc_hip_solve_tree_shard(mpc_hip_handle *h, const mpc_problem *h_pro
  * pieces -- slices of the deepest level that is stored in full, searched one after the other on this handle without
  * expanding anything above them again, as many as make a piece's leaves fit -- and the pieces' winners are combined as
  * the shards' are: the smallest (strict score, global DFS ordinal).  Depth 8 (5.2e9 leaves) takes 7-11 ms
- * (MPC_PREC_FAST) on one MI355X, depth 9 (8.8e10) 93-132 ms.  A level counts only if all its pieces finished before
+ * (MPC_PREC_FAST) on one MI355X, depth 9 (8.8e10) 87-126 ms.  A level counts only if all its pieces finished before
  * end_time (controller.cpp:101-103: an unfinished iteration is discarded); h_level_best / h_result then stay the
  * previous level's -- and the level is given up as soon as its remaining pieces, at the pace of those done, would end
  * after it.  now == NULL runs to max_levels whatever that takes.  Results are those of one search of the same depth:
