@@ -252,6 +252,33 @@ static void mpcMatchesOracle(double planSeconds, double cx, double cy)
     }
 }
 
+/* A plan long enough for eight levels (5.2e9 leaves: beyond one expansion; the drop-in calls mpc_hip_solve_tree_deep, which
+ * searches the level in pieces).  No oracle for that depth (45 min): what is checked is that all eight levels come back,
+ * that the first step IS the reference's simulate() of the chosen control from the start state (this side's
+ * VehicleState, the reference's arithmetic), and that the chosen control is one of the start state's control set. */
+static void mpcLooksEightSecondsAhead()
+{
+    NodeStub stub(true, 1000.0);                               /* frozen clock: depth is set by the plan length */
+    Controller c(&stub);
+    c.updateConfig(0.0625, 0.125, 1, 20, 5, 20, true, 5);
+    c.updateDisturbanceEstimate(0.1, -0.05);
+    c.setTrajectoryNumber(11);
+    DubinsPlan plan = semicircle(nullptr, 9.5);
+    State start(0, 0, 0, 2.5, 4);
+    Controller::MpcState got = c.mpc(start, plan, 1e18, 11);
+    CHECK(stub.displayed == 1 && (int)stub.lastTrajectory.size() == 9);
+    for (int l = 0; l < (int)stub.lastTrajectory.size(); l++) CHECK(std::fabs(stub.lastTrajectory[l].time() - (4.0 + l)) < 1e-9);
+    VehicleState first = VehicleState(start).simulate(got.LastRudder, got.LastThrottle, 1.0, std::make_pair(0.1, -0.05));
+    CHECK(std::fabs(first.state.x() - got.state.state.x()) <= 1e-12 && std::fabs(first.state.y() - got.state.state.y()) <= 1e-12);
+    CHECK(std::fabs(first.state.heading() - got.state.state.heading()) <= 1e-12 && std::fabs(first.rpm - got.state.rpm) <= 1e-9);
+    const double r = got.LastRudder, t = got.LastThrottle;     /* the root's control set (controller.cpp:121-146, last controls 0, 0) */
+    CHECK(r == -1 || r == 0 || r == 1 || r == -0.0625 || r == 0.0625);
+    CHECK(t == 0 || t == 1 || t == 0.125);
+    /* the whole predicted path stays near the plan: the eighth state within a few metres of the plan's eighth checkpoint */
+    State cp; cp.time() = 12.0; plan.sample(cp);
+    CHECK(std::hypot(stub.lastTrajectory[8].x() - cp.x(), stub.lastTrajectory[8].y() - cp.y()) < 3.0);
+}
+
 static void mpcErrorBehaviour()
 {
     NodeStub stub(true, 1000.0);
@@ -469,6 +496,7 @@ int main(int argc, char** argv)
         mpcMatchesOracle(4.5, 0.2, -0.1);
         mpcMatchesOracle(5.5, 0.2, -0.1);
         mpcMatchesOracle(6.5, 0.0, 0.0);
+        mpcLooksEightSecondsAhead();
         mpcErrorBehaviour();
         mpcWithSecondHull();
         twoOverlappingSolves(4.5, 7.5, 100);          /* depth 3: the strict model expands; depth 6: the streamlined one */
