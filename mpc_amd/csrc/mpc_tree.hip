@@ -286,6 +286,9 @@ __device__ inline bool margin_beyond(float margin, double dmax) { return margin 
  * children from parents reports +inf for a ghost's. */
 __device__ inline bool is_ghost(const LevelPtrs &A, uint32_t par) { return A.margin[par] == MARGIN_GHOST; }
 
+/* one past a tile's last child, without wrapping for the last tile of a level of nearly 2^32 children */
+__device__ inline uint32_t tile_end_of(uint32_t tile) { return tile + 1 < (1u << 24) ? (tile + 1) * 256 : 0xFFFFFFFFu; }
+
 /* wave 0 of a workgroup, all 64 lanes: the smallest margin among the parents of one tile (lane i holds parent par0 + i's
  * offset; parents whose children begin at or after tile_end, and lanes past the level, do not belong to the tile) */
 __device__ inline float tile_margin(const LevelPtrs &A, uint32_t par, uint32_t n_parent, uint32_t off, uint32_t tile_end)
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
         win[0][threadIdx.x] = off;
-        if (!STORE) { const float m = tile_margin(A, p, n_parent, off, (tile0 + 1) * 256); if (threadIdx.x == 0) s_margin[0] = m; }
+        if (!STORE) { const float m = tile_margin(A, p, n_parent, off, tile_end_of(tile0)); if (threadIdx.x == 0) s_margin[0] = m; }
     }
     if (!STORE && threadIdx.x == 0) s_dmax[0] = tree_bound_read(bound);
     stage_problem(P, cpL, subL);                                     /* ends with a barrier */
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const DevProblem *__restric
         if (more) {
             if (threadIdx.x < PARENT_WINDOW) {
                 win[(i + 1) & 1][threadIdx.x] = off_next;
-                if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
+                if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, tile_end_of(tile_next)); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
             }
             if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
             par0 = par_next; tile = tile_next;
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
     if (threadIdx.x < PARENT_WINDOW) {
         const uint32_t p = min(par0 + threadIdx.x, n_parent), off = A.offset[p];
         win[0][threadIdx.x] = off;
-        if (!STORE) { const float m = tile_margin(A, p, n_parent, off, (tile0 + 1) * 256); if (threadIdx.x == 0) s_margin[0] = m; }
+        if (!STORE) { const float m = tile_margin(A, p, n_parent, off, tile_end_of(tile0)); if (threadIdx.x == 0) s_margin[0] = m; }
     }
     if (!STORE && threadIdx.x == 0) s_dmax[0] = tree_bound_read(bound);
     stage_problem(P, cpL, subL);
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(const DevProblem *__re
             if (more) {
                 if (threadIdx.x < PARENT_WINDOW) {
                     win[(i + 1) & 1][threadIdx.x] = off_next;
-                    if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, (tile_next + 1) * 256); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
+                    if (!STORE) { const float m = tile_margin(A, p_next, n_parent, off_next, tile_end_of(tile_next)); if (threadIdx.x == 0) s_margin[(i + 1) & 1] = m; }
                 }
                 if (!STORE && threadIdx.x == 0) s_dmax[(i + 1) & 1] = tree_bound_read(bound);
                 par0 = par_next; tile = tile_next;
