@@ -1787,9 +1787,14 @@ extern "C" int mpc_hip_solve_tree_deep(mpc_hip_handle *h, const mpc_problem *h_p
 {
     if (!h || !h_problem || !h_result) { mpc_set_err("solve_tree_deep: NULL argument"); return MPC_ERR_INVALID; }
     std::vector<mpc_tree_level> lv((size_t)std::max(max_levels, 1));
-    int s = solve_tree_checked(h, h_problem, max_levels, precision, now, now_ctx, end_time, 0, 0, 0, 1, lv.data(), h_result);
+    /* diagnostic: MPC_HIP_TREE_DEEP_FROM=k lets the plain search end at level k as if level k + 1 did not fit, so that the
+     * random runs of tools/fuzz_tree.py reach the pieces with trees the oracle can enumerate */
+    static const int deep_from = getenv("MPC_HIP_TREE_DEEP_FROM") ? atoi(getenv("MPC_HIP_TREE_DEEP_FROM")) : 0;
+    const bool forced = deep_from >= 2 && max_levels > deep_from;
+    int s = solve_tree_checked(h, h_problem, forced ? deep_from : max_levels, precision, now, now_ctx, end_time, 0, 0, 0, 1, lv.data(), h_result);
     if (s != MPC_OK) return s;
     int L = h_result->levels;
+    if (forced && L == deep_from) h->tree_stopped_by_width = true;
     if (h_level_best) for (int l = 0; l < L; l++) h_level_best[l] = lv[(size_t)l];
     const uint64_t nsub = (uint64_t)h_problem->n_substeps;
     std::vector<mpc_tree_level> plv((size_t)std::max(max_levels, 1));

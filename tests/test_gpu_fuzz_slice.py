@@ -59,6 +59,20 @@ def test_tree_slice_through_the_final_levels_short_list():
     assert summary and "tree problems 120 ; disagreements WITHOUT the libm_tie flag 0 ;" in summary[0], r.stdout[-3000:]
 
 
+def test_tree_slice_through_the_pieces():
+    """mpc_hip_solve_tree_deep searches levels beyond one expansion in pieces that resume from the stored levels, share one
+    bound and look for the level's one winner (mpc_tree.hip: TreeResume).  Real trees reach that at depth 8; here a child
+    process lets the plain search end at level 2 (MPC_HIP_TREE_DEEP_FROM) so that levels 3 and 4 of 100 random trees with
+    random boats go through the pieces -- against the oracle's enumeration"""
+    import subprocess
+    env = dict(os.environ, MPC_HIP_TREE_SYNC_LEVELS="1", MPC_HIP_TREE_LIST_MIN="1", MPC_HIP_TREE_DEEP_FROM="2")
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "fuzz_tree.py"), "100", "20268", "hulls", "deep"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("tree problems")]
+    assert summary and "tree problems 100 ; disagreements WITHOUT the libm_tie flag 0 ;" in summary[0], r.stdout[-3000:]
+
+
 def test_explicit_slice(solver):
     import fuzz_explicit
     out = fuzz_explicit.run(200, seed=20264, solver=solver, verbose=False, sizes=(1, 63, 64, 65, 300, 1000))

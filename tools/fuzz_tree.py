@@ -1,6 +1,7 @@
 """A long random run of the tree search against the oracle's DFS (python tools/fuzz_tree.py [problems] [seed]): random
 start states, last controls, currents, weights (some zero), granularities and Dubins references; depths 2-4 (the oracle's
-depth 4 costs 33 ms); both expansions; with a third argument "hulls", a random boat per problem.  Prints every disagreement instead of stopping at the first.  A chosen leaf that differs from the
+depth 4 costs 33 ms); both expansions; further arguments: "hulls" = a random boat per problem, "deep" = through
+mpc_hip_solve_tree_deep (with MPC_HIP_TREE_DEEP_FROM=2: levels 3 and 4 in pieces).  Prints every disagreement instead of stopping at the first.  A chosen leaf that differs from the
 oracle's counts as a disagreement only if the level does not carry libm_tie (mpc_hip.h: the strict runner-up within 2 ulps:
 the choice then depends on whose sin/cos/atan2/exp evaluated it)."""
 import math
@@ -58,7 +59,7 @@ def draw_hull(rng):
             return h
 
 
-def run(n_problems=200, seed=7, solver=None, verbose=True, max_depth=4, hulls=False):
+def run(n_problems=200, seed=7, solver=None, verbose=True, max_depth=4, hulls=False, deep=False):
     """-> dict(problems, bad = [disagreements that do NOT carry libm_tie], libm_ties = [flagged leaf disagreements], worst)
     hulls: every problem with a boat of its own (draw_hull), on the library's side and the oracle's"""
     rng = np.random.RandomState(seed)
@@ -66,14 +67,17 @@ def run(n_problems=200, seed=7, solver=None, verbose=True, max_depth=4, hulls=Fa
     bad, flagged, worst = [], [], 0.0
     t0 = time.time()
     try:
-        return _run(n_problems, rng, solver, verbose, max_depth, hulls, bad, flagged, worst, t0)
+        return _run(n_problems, rng, solver, verbose, max_depth, hulls, bad, flagged, worst, t0, deep)
     finally:
         if hulls:
             O.set_model()
             solver.set_model(M.default_model())
 
 
-def _run(n_problems, rng, solver, verbose, max_depth, hulls, bad, flagged, worst, t0):
+def _run(n_problems, rng, solver, verbose, max_depth, hulls, bad, flagged, worst, t0, deep=False):
+    # deep: through mpc_hip_solve_tree_deep -- with MPC_HIP_TREE_DEEP_FROM=2 in the environment (and the switches that send
+    # shallow levels the synchronised way and through list and ghosts) levels 3 and 4 are then searched in pieces
+    solve = solver.solve_tree_deep if deep else solver.solve_tree
     for k in range(n_problems):
         p, depth, w = draw(rng, max_depth)
         if hulls:
@@ -85,7 +89,7 @@ def _run(n_problems, rng, solver, verbose, max_depth, hulls, bad, flagged, worst
         results = []
         for prec in (M.PREC_F64, M.PREC_FAST):
             try:
-                res, levels = solver.solve_tree(p, depth, precision=prec)
+                res, levels = solve(p, depth, precision=prec)
             except M.MpcError as e:
                 # a drawn hull that turns faster than the fast model's polynomials cover: the library says so, strict only
                 if hulls and prec == M.PREC_FAST and "does not cover this hull" in str(e):
@@ -129,7 +133,7 @@ def _run(n_problems, rng, solver, verbose, max_depth, hulls, bad, flagged, worst
 
 if __name__ == "__main__":
     out = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
-              hulls=len(sys.argv) > 3 and sys.argv[3] == "hulls")
+              hulls="hulls" in sys.argv[3:], deep="deep" in sys.argv[3:])
     print("tree problems", out["problems"], "; disagreements WITHOUT the libm_tie flag", len(out["bad"]),
           "; leaf choices that differ from the oracle's and carry libm_tie", len(out["libm_ties"]),
           "; worst relative error of a level's best score", out["worst"])
